@@ -1,0 +1,173 @@
+/*
+ * mrt.h -- C-ABI of libmrt.so, the MI355X (gfx950) back end of the render hot path.
+ *
+ * This is the drop-in boundary.  The reference has no FFI; its de-facto boundary
+ * is the set of CUDA-runtime touch points funnelled through include/cuda_utils/
+ * and src/check_error.cu (reference paths below are relative to its checkout).
+ * Each entry point cites the touch point it replaces.  HIP is visible only
+ * inside the library: signatures carry plain pointers and sizes.
+ *
+ * Conventions
+ *  - every function returns MRT_OK (0) or a negative mrt_status; nothing exits
+ *    or throws (the fail-fast print-and-exit convention of src/check_error.cu:7-15
+ *    lives on the C++ side as checkRtErrors(), raytracing_amd/host/hip_utils/check_error.hpp);
+ *  - one context drives ONE GPU (one process per GPU; multi-GPU frames are split
+ *    in strips by the caller, see mrt_partition);
+ *  - calls on one context are serialised by the caller (the reference is single
+ *    threaded, src/main.cu:159-260);
+ *  - all arithmetic is fp32 with FMA contraction off and IEEE div/sqrt, in the
+ *    operation order documented in DESIGN.md, so hit/ID buffers are bit-comparable
+ *    with the CPU oracle.
+ */
+#ifndef MRT_H
+#define MRT_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum mrt_status {
+  MRT_OK = 0,
+  MRT_ERR_INVALID = -1,   /* bad argument (null pointer, size mismatch, unsupported mode) */
+  MRT_ERR_HIP = -2,       /* a HIP runtime call failed; mrt_last_error() has the text */
+  MRT_ERR_NO_SCENE = -3,  /* render before mrt_scene_upload */
+  MRT_ERR_NO_DEVICE = -4, /* no usable GPU */
+  MRT_ERR_TOO_LARGE = -5  /* size beyond a documented limit */
+} mrt_status;
+
+enum { MRT_GEOM_SPHERE = 0, MRT_GEOM_PLANE = 1, MRT_GEOM_TRIANGLE = 2 }; /* core/scene_object.cuh:14 */
+enum { MRT_MAT_DIFFUSE = 0, MRT_MAT_METALLIC = 1 };                      /* core/scene_object.cuh:16 */
+enum { MRT_LIGHT_DIRECTIONAL = 0, MRT_LIGHT_POINT = 1 };                 /* core/light.cuh:60, :36 */
+
+typedef struct mrt_ctx mrt_ctx;
+
+/*
+ * Scene as the reference's kernel consumes it, flattened to SoA host arrays.
+ * Replaces rt::Vector<rt::SceneObject> / rt::Vector<rt::DirectionalLight> in
+ * managed memory (container/vector.cuh:15-177, built at src/main.cu:210-237).
+ * The library copies everything; the caller keeps ownership.
+ *
+ * Objects are numbered 0..num_objects-1 in scene order; closest-hit ties and
+ * the ID buffer are defined on that number (src/main.cu:67-77).
+ * Planes (core/plane.cuh:25-29) never hit, so they only occupy an object number.
+ */
+typedef struct mrt_scene_desc {
+  int32_t num_objects;
+  const uint8_t *mat_kind;  /* [num_objects] MRT_MAT_* */
+  const float *mat_rgb;     /* [num_objects*3] material colour (core/material.cuh:78, :160) */
+
+  int32_t num_spheres;
+  const float *sphere_cx, *sphere_cy, *sphere_cz, *sphere_r; /* [num_spheres] each (core/sphere.cuh:116-117) */
+  const int32_t *sphere_obj;                                 /* [num_spheres] object number, ascending */
+
+  int32_t num_triangles;
+  /* 16 streams of [num_triangles], stream s at tri + s*num_triangles: the state the
+   * Triangle constructor leaves behind (core/triangle.cuh:58-66, :118-122):
+   * 0-2 plane normal, 3 plane intercept, then three edge discriminators
+   * (normal xyz, intercept) for ab|c, bc|a, ca|b */
+  const float *tri;
+  const int32_t *tri_obj; /* [num_triangles] object number, ascending */
+
+  int32_t num_lights;
+  const uint8_t *light_kind; /* [num_lights] MRT_LIGHT_* */
+  const float *light_vec;    /* [num_lights*3] unit direction (directional) or position (point) */
+  const float *light_rgb;    /* [num_lights*3] */
+} mrt_scene_desc;
+
+/* rt::Viewport after construction (pipeline/viewport.cuh:43-47), computed on the host */
+typedef struct mrt_camera {
+  float origin[3];
+  float horizontal[3];
+  float vertical[3];
+  float up_left[3];
+} mrt_camera;
+
+/*
+ * Strip partition of a frame over ranks (no reference counterpart: the reference is
+ * single GPU).  Rows are dealt in strips of strip_rows rows,
+ * strip s -> rank s % num_ranks.  A rank's local buffer holds its strips back to
+ * back in ascending order.  {0,1,8} renders the whole frame.
+ */
+typedef struct mrt_partition {
+  int32_t rank;
+  int32_t num_ranks;
+  int32_t strip_rows; /* multiple of 8 */
+} mrt_partition;
+
+typedef struct mrt_render_params {
+  int32_t width, height;  /* full frame */
+  int32_t spp;            /* 1: one sample at (col/W,row/H); 121: rt::MultisampleMesh (pipeline/multisample_mesh.cuh) */
+  int32_t max_depth;      /* config::MAX_RECURSION_DEPTH (src/main.cu:26); 0 = primary + shadow */
+  mrt_partition part;
+} mrt_render_params;
+
+typedef struct mrt_stats {
+  uint64_t primary_rays; /* local pixels * spp */
+  uint64_t shadow_rays;  /* lights passing the L.N >= 0 test (core/light.cuh:148) */
+  uint64_t hit_pixels;
+  uint64_t occluded;
+  float kernel_ms;       /* HIP-event time of the render kernel(s) */
+} mrt_stats;
+
+/* --- device / context: replaces the implicit device 0 + cudaDeviceReset of src/check_error.cu:12 */
+int mrt_device_count(int *count);
+int mrt_ctx_create(int device, mrt_ctx **out);
+int mrt_ctx_destroy(mrt_ctx *ctx);
+/* last error text of this context (or of the failed create when ctx is NULL); never NULL */
+const char *mrt_last_error(const mrt_ctx *ctx);
+const char *mrt_status_string(int status);
+
+/* --- scene: replaces cudaMallocManaged-backed rt::Vector (container/vector.cuh:26,131) */
+int mrt_scene_upload(mrt_ctx *ctx, const mrt_scene_desc *scene);
+
+/* number of local rows a rank renders under a partition (host helper, like
+ * rt::make_work_partition, cuda_utils/work_partition.cuh:12-23) */
+int mrt_local_rows(int32_t height, const mrt_partition *part, int32_t *rows);
+
+/*
+ * Blocking render into HOST buffers: replaces render<<<>>> + cudaGetLastError +
+ * cudaDeviceSynchronize (src/main.cu:239-247) and the managed ImageBuffer
+ * (container/alloc.cuh:13-106).  Buffers hold the rank's local rows:
+ * rgb [rows*W*3] linear float RGB, row 0 = v 0 (the reference's pre-flip order);
+ * id [rows*W] object number or -1; t [rows*W] closest-hit parameter or +inf.
+ * id/t/stats may be NULL.
+ */
+int mrt_render(mrt_ctx *ctx, const mrt_camera *cam, const mrt_render_params *params, float *rgb, int32_t *id,
+               float *t, mrt_stats *stats);
+
+/*
+ * Asynchronous render into DEVICE buffers on a caller-supplied HIP stream
+ * (hipStream_t passed as void*, NULL = the context's own stream).  Same layout
+ * as mrt_render.  stats_dev, if not NULL, points to 4 device uint64 that receive
+ * primary/shadow/hit/occluded counts.  The caller synchronises.
+ */
+int mrt_render_device(mrt_ctx *ctx, const mrt_camera *cam, const mrt_render_params *params, void *rgb_dev,
+                      void *id_dev, void *t_dev, void *stats_dev, void *stream);
+
+/*
+ * Rank 0, after the gather: scatter the ranks' strip buffers (rank r's buffer at
+ * gathered + r*rank_stride elements... see DESIGN.md) into one row-major frame.
+ * elem_floats = 3 for rgb, 1 for id/t (4-byte elements).  Device pointers.
+ */
+int mrt_assemble_strips(mrt_ctx *ctx, const void *gathered_dev, size_t rank_stride_elems, void *frame_dev,
+                        int32_t width, int32_t height, int32_t elem_dwords, int32_t num_ranks, int32_t strip_rows,
+                        void *stream);
+
+/*
+ * Batched single-primitive intersection on the GPU: replaces the test kernels
+ * hit_sphere / hit_triangle <<<1,1>>> (test/spheretest.cu:6-12, test/triangletest.cu:6-12).
+ * prim: 4 floats (cx,cy,cz,r) for a sphere, 16 floats (layout of mrt_scene_desc.tri,
+ * one triangle) for a triangle.  rays [n*6] = origin xyz, direction xyz.
+ * Closed interval [tmin,tmax] (core/interval.cuh:28-29).  Host pointers; outputs
+ * hit [n], t [n], point [n*3], normal [n*3]; entries of non-hits are left zero.
+ */
+int mrt_intersect(mrt_ctx *ctx, int prim_kind, const float *prim, const float *rays, float tmin, float tmax,
+                  int64_t n, uint8_t *hit, float *t, float *point, float *normal);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,61 @@
+// mrt_internal.h -- shared between the C-ABI (mrt_api.cpp) and the gfx950 kernels (mrt_kernels.hip).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace mrt {
+
+// Scene as it lives in HBM: pure SoA streams, one allocation per group.
+struct DevScene {
+  // spheres: 4 streams of ns floats (core/sphere.cuh:116-117) + object numbers
+  const float *sph_cx, *sph_cy, *sph_cz, *sph_r;
+  const int32_t *sph_obj;
+  int32_t ns;
+  // triangles: 16 streams of nt floats, stream s at tri + s*nt (core/triangle.cuh:118-122)
+  const float *tri;
+  const int32_t *tri_obj;
+  int32_t nt;
+  // per object material (core/material.cuh:78,160)
+  const uint8_t *mat_kind;
+  const float *mat_rgb; // [nobj*3]
+  int32_t nobj;
+  // lights (core/light.cuh:56-57, :84-85)
+  const uint8_t *light_kind;
+  const float *light_vec; // [nl*3]
+  const float *light_rgb; // [nl*3]
+  int32_t nl;
+};
+
+struct DevCamera {
+  float ox, oy, oz;
+  float hx, hy, hz;
+  float vx, vy, vz;
+  float ux, uy, uz; // up_left
+};
+
+struct RenderArgs {
+  DevScene sc;
+  DevCamera cam;
+  int32_t W, H;
+  int32_t rank, nranks, strip_rows; // strip partition
+  int32_t local_rows;
+  int32_t spp;                      // 1 or 121
+  float *rgb;                       // [local_rows*W*3]
+  int32_t *id;                      // [local_rows*W] or null
+  float *t;                         // [local_rows*W] or null
+  unsigned long long *stats;        // 4 counters or null
+  // LDS plan (filled by the launcher)
+  int32_t resident;                 // whole scene staged once
+  int32_t s_cap, t_cap;             // primitives per LDS chunk
+};
+
+// launchers (mrt_kernels.hip)
+hipError_t launch_render(const RenderArgs &args, hipStream_t stream);
+hipError_t launch_intersect(int prim_kind, const float *prim_dev, const float *rays_dev, float tmin, float tmax,
+                            int64_t n, uint8_t *hit_dev, float *t_dev, float *point_dev, float *normal_dev,
+                            hipStream_t stream);
+hipError_t launch_assemble(const uint32_t *gathered, size_t rank_stride_elems, uint32_t *frame, int W, int H,
+                           int elem_dwords, int nranks, int strip_rows, hipStream_t stream);
+
+} // namespace mrt

@@ -1,0 +1,209 @@
+"""ctypes binding of oracle/librt_oracle.so -- TEST INFRASTRUCTURE ONLY.
+
+Importable from tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg,
+and from nowhere else (the product package never imports it).
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+ORACLE_DIR = os.path.join(os.path.dirname(_HERE), "oracle")
+_LIB_PATH = os.path.join(ORACLE_DIR, "librt_oracle.so")
+
+GEOM_SPHERE, GEOM_PLANE, GEOM_TRIANGLE = 0, 1, 2
+MAT_DIFFUSE, MAT_METALLIC = 0, 1
+LIGHT_DIRECTIONAL, LIGHT_POINT = 0, 1
+
+
+class OrcStats(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in ("primary_rays", "shadow_rays", "hit_pixels", "occluded", "lit")]
+
+    def as_dict(self):
+        return {n: int(getattr(self, n)) for n, _ in self._fields_}
+
+
+_f3 = C.POINTER(C.c_float)
+
+
+def _load():
+    if not os.path.exists(_LIB_PATH):
+        subprocess.check_call(["make", "-C", ORACLE_DIR], stdout=subprocess.DEVNULL)
+    lib = C.CDLL(_LIB_PATH)
+    lib.orc_scene_create.restype = C.c_void_p
+    lib.orc_scene_destroy.argtypes = [C.c_void_p]
+    lib.orc_scene_num_objects.argtypes = [C.c_void_p]
+    lib.orc_scene_num_lights.argtypes = [C.c_void_p]
+    lib.orc_add_sphere.argtypes = [C.c_void_p, _f3, C.c_float, C.c_int, _f3]
+    lib.orc_add_triangle.argtypes = [C.c_void_p, _f3, _f3, _f3, C.c_int, _f3]
+    lib.orc_add_plane.argtypes = [C.c_void_p, C.c_float, _f3, C.c_int, _f3]
+    lib.orc_add_directional_light.argtypes = [C.c_void_p, _f3, _f3]
+    lib.orc_add_point_light.argtypes = [C.c_void_p, _f3, _f3]
+    lib.orc_build_default_scene.argtypes = [C.c_void_p]
+    lib.orc_viewport.argtypes = [_f3, _f3, _f3, C.c_float, C.c_float, _f3]
+    lib.orc_triangle_precompute.argtypes = [_f3, _f3, _f3, _f3]
+    lib.orc_sphere_hit.argtypes = [_f3, C.c_float, _f3, _f3, C.c_float, C.c_float, _f3, _f3, _f3]
+    lib.orc_triangle_hit.argtypes = [_f3, _f3, _f3, _f3, _f3, C.c_float, C.c_float, _f3, _f3, _f3]
+    lib.orc_triangle16_hit.argtypes = [_f3, _f3, _f3, C.c_float, C.c_float, _f3, _f3, _f3]
+    lib.orc_render.argtypes = [C.c_void_p, _f3, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                               C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(OrcStats)]
+    return lib
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        _lib = _load()
+    return _lib
+
+
+def _v(a):
+    arr = (C.c_float * len(a))(*[float(x) for x in a])
+    return arr
+
+
+class Scene:
+    """AoS scene of the oracle (mirrors rt::Vector<rt::SceneObject> + lights)."""
+
+    def __init__(self):
+        self._h = C.c_void_p(lib().orc_scene_create())
+
+    def __del__(self):
+        try:
+            if self._h:
+                lib().orc_scene_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    @classmethod
+    def default(cls):
+        s = cls()
+        lib().orc_build_default_scene(s._h)
+        return s
+
+    @classmethod
+    def from_desc(cls, desc):
+        """desc: the dict produced by raytracing_amd.scenes generators."""
+        s = cls()
+        for o in desc["objects"]:
+            if o["geom"] == "sphere":
+                s.add_sphere(o["c"], o["r"], o["mat"], o["rgb"])
+            elif o["geom"] == "triangle":
+                s.add_triangle(o["a"], o["b"], o["c"], o["mat"], o["rgb"])
+            else:
+                s.add_plane(o["k"], o["n"], o["mat"], o["rgb"])
+        for l in desc["lights"]:
+            if l["kind"] == LIGHT_DIRECTIONAL:
+                s.add_directional_light(l["v"], l["rgb"])
+            else:
+                s.add_point_light(l["v"], l["rgb"])
+        return s
+
+    def add_sphere(self, c, r, mat, rgb):
+        return lib().orc_add_sphere(self._h, _v(c), float(r), int(mat), _v(rgb))
+
+    def add_triangle(self, a, b, c, mat, rgb):
+        return lib().orc_add_triangle(self._h, _v(a), _v(b), _v(c), int(mat), _v(rgb))
+
+    def add_plane(self, k, n, mat, rgb):
+        return lib().orc_add_plane(self._h, float(k), _v(n), int(mat), _v(rgb))
+
+    def add_directional_light(self, d, rgb):
+        return lib().orc_add_directional_light(self._h, _v(d), _v(rgb))
+
+    def add_point_light(self, p, rgb):
+        return lib().orc_add_point_light(self._h, _v(p), _v(rgb))
+
+    @property
+    def num_objects(self):
+        return lib().orc_scene_num_objects(self._h)
+
+    @property
+    def num_lights(self):
+        return lib().orc_scene_num_lights(self._h)
+
+    def add_soa(self, spheres, sphere_obj, tri_verts, tri_obj, mat_kind, mat_rgb, lights):
+        """Bulk insert in object order from arrays (used for the large synthetic scenes)."""
+        n = len(mat_kind)
+        order = np.full(n, -1, dtype=np.int64)
+        kind = np.zeros(n, dtype=np.int8)
+        order[np.asarray(sphere_obj, dtype=np.int64)] = np.arange(len(sphere_obj))
+        if len(tri_obj):
+            order[np.asarray(tri_obj, dtype=np.int64)] = np.arange(len(tri_obj))
+            kind[np.asarray(tri_obj, dtype=np.int64)] = 2
+        L = lib()
+        sp = np.ascontiguousarray(spheres, dtype=np.float32)
+        tv = np.ascontiguousarray(tri_verts, dtype=np.float32)
+        rgb = np.ascontiguousarray(mat_rgb, dtype=np.float32)
+        fp = lambda a: a.ctypes.data_as(_f3)
+        for i in range(n):
+            j = int(order[i])
+            col = rgb[i]
+            if kind[i] == 0:
+                L.orc_add_sphere(self._h, fp(sp[j, :3]), float(sp[j, 3]), int(mat_kind[i]), fp(col))
+            else:
+                L.orc_add_triangle(self._h, fp(tv[j, 0]), fp(tv[j, 1]), fp(tv[j, 2]), int(mat_kind[i]), fp(col))
+        for (k, v, c) in lights:
+            if k == LIGHT_DIRECTIONAL:
+                self.add_directional_light(v, c)
+            else:
+                self.add_point_light(v, c)
+
+    def render(self, cam12, W, H, rows=None, spp=1, max_depth=0, nthreads=1, want=("rgb", "id", "t")):
+        cam = np.ascontiguousarray(cam12, dtype=np.float32)
+        r0, r1 = (0, H) if rows is None else rows
+        rgb = np.zeros((H, W, 3), dtype=np.float32) if "rgb" in want else None
+        ids = np.full((H, W), -2, dtype=np.int32) if "id" in want else None
+        t = np.zeros((H, W), dtype=np.float32) if "t" in want else None
+        st = OrcStats()
+        p = lambda a: a.ctypes.data_as(C.c_void_p) if a is not None else None
+        rc = lib().orc_render(self._h, cam.ctypes.data_as(_f3), W, H, r0, r1, spp, max_depth, nthreads,
+                              p(rgb), p(ids), p(t), C.byref(st))
+        if rc != 0:
+            raise RuntimeError(f"orc_render failed: {rc}")
+        return {"rgb": rgb, "id": ids, "t": t, "stats": st.as_dict()}
+
+
+def viewport(look_from, look_at, up, vfov_deg, aspect):
+    out = (C.c_float * 12)()
+    lib().orc_viewport(_v(look_from), _v(look_at), _v(up), float(vfov_deg), float(aspect), out)
+    return np.array(out[:], dtype=np.float32)
+
+
+def default_viewport(aspect=2.0):
+    """config::make_viewport(), src/main.cu:34-41 (aspect 2.0 there)."""
+    return viewport((0.0, 4.0, 6.0), (0.0, 0.0, -20.0), (0.0, 1.0, 0.0), 20.0, aspect)
+
+
+def triangle_precompute(a, b, c):
+    out = (C.c_float * 16)()
+    lib().orc_triangle_precompute(_v(a), _v(b), _v(c), out)
+    return np.array(out[:], dtype=np.float32)
+
+
+def _hit_out():
+    return C.c_float(), (C.c_float * 3)(), (C.c_float * 3)()
+
+
+def sphere_hit(c, r, ro, rd, tmin, tmax):
+    t, p, n = _hit_out()
+    ok = lib().orc_sphere_hit(_v(c), float(r), _v(ro), _v(rd), float(tmin), float(tmax), C.byref(t), p, n)
+    return (bool(ok), np.float32(t.value), np.array(p[:], np.float32), np.array(n[:], np.float32))
+
+
+def triangle_hit(a, b, c, ro, rd, tmin, tmax):
+    t, p, n = _hit_out()
+    ok = lib().orc_triangle_hit(_v(a), _v(b), _v(c), _v(ro), _v(rd), float(tmin), float(tmax), C.byref(t), p, n)
+    return (bool(ok), np.float32(t.value), np.array(p[:], np.float32), np.array(n[:], np.float32))
+
+
+def triangle16_hit(q, ro, rd, tmin, tmax):
+    t, p, n = _hit_out()
+    ok = lib().orc_triangle16_hit(_v(q), _v(ro), _v(rd), float(tmin), float(tmax), C.byref(t), p, n)
+    return (bool(ok), np.float32(t.value), np.array(p[:], np.float32), np.array(n[:], np.float32))
