@@ -502,6 +502,20 @@ int orc_add_plane(orc_scene *s, float intercept, const float n[3], int mat_kind,
   return s->nobj - 1;
 }
 
+int orc_add_objects(orc_scene *s, int n, const uint8_t *geom_kind, const float *geom9, const uint8_t *mat_kind,
+                    const float *mat_rgb)
+{
+  for (int i = 0; i < n; ++i) {
+    const float *g = geom9 + 9 * (size_t)i;
+    int rc;
+    if (geom_kind[i] == ORC_GEOM_SPHERE) rc = orc_add_sphere(s, g, g[3], mat_kind[i], mat_rgb + 3 * (size_t)i);
+    else if (geom_kind[i] == ORC_GEOM_TRIANGLE) rc = orc_add_triangle(s, g, g + 3, g + 6, mat_kind[i], mat_rgb + 3 * (size_t)i);
+    else rc = orc_add_plane(s, g[3], g, mat_kind[i], mat_rgb + 3 * (size_t)i);
+    if (rc < 0) return rc;
+  }
+  return 0;
+}
+
 /* core/light.cuh:64-67: the constructor normalises the direction */
 int orc_add_directional_light(orc_scene *s, const float dir[3], const float rgb[3])
 {

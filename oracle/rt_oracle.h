@@ -66,6 +66,11 @@ int orc_add_plane(orc_scene *s, float intercept, const float n[3], int mat_kind,
 int orc_add_directional_light(orc_scene *s, const float dir[3], const float rgb[3]);
 int orc_add_point_light(orc_scene *s, const float pos[3], const float rgb[3]);
 
+/* bulk insert of n objects in scene order: geom_kind[i] is ORC_GEOM_SPHERE (geom9 = cx,cy,cz,r,...)
+ * or ORC_GEOM_TRIANGLE (geom9 = a.xyz,b.xyz,c.xyz); 9 floats per object either way */
+int orc_add_objects(orc_scene *s, int n, const uint8_t *geom_kind, const float *geom9, const uint8_t *mat_kind,
+                    const float *mat_rgb);
+
 /* the scene and light hard-coded in src/main.cu:183-237 */
 void orc_build_default_scene(orc_scene *s);
 

@@ -1,0 +1,353 @@
+"""ctypes binding of libmrt.so (include/mrt.h) and libmrt_host.so (host/host_capi.cpp).
+
+No fallback of any kind: if a library is missing or a call fails, this raises.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_DIR = os.path.join(_HERE, "lib")
+LIBMRT_PATH = os.path.join(LIB_DIR, "libmrt.so")
+LIBHOST_PATH = os.path.join(LIB_DIR, "libmrt_host.so")
+
+GEOM_SPHERE, GEOM_PLANE, GEOM_TRIANGLE = 0, 1, 2
+MAT_DIFFUSE, MAT_METALLIC = 0, 1
+LIGHT_DIRECTIONAL, LIGHT_POINT = 0, 1
+
+# every symbol include/mrt.h declares (tests check the library exports all of them)
+MRT_SYMBOLS = [
+    "mrt_device_count", "mrt_ctx_create", "mrt_ctx_destroy", "mrt_last_error", "mrt_status_string",
+    "mrt_scene_upload", "mrt_local_rows", "mrt_render", "mrt_render_device", "mrt_assemble_strips",
+    "mrt_intersect",
+]
+
+_f = C.POINTER(C.c_float)
+_i32 = C.POINTER(C.c_int32)
+_u8 = C.POINTER(C.c_uint8)
+
+
+class MrtError(RuntimeError):
+    pass
+
+
+class SceneDesc(C.Structure):
+    _fields_ = [
+        ("num_objects", C.c_int32), ("mat_kind", _u8), ("mat_rgb", _f),
+        ("num_spheres", C.c_int32), ("sphere_cx", _f), ("sphere_cy", _f), ("sphere_cz", _f), ("sphere_r", _f),
+        ("sphere_obj", _i32),
+        ("num_triangles", C.c_int32), ("tri", _f), ("tri_obj", _i32),
+        ("num_lights", C.c_int32), ("light_kind", _u8), ("light_vec", _f), ("light_rgb", _f),
+    ]
+
+
+class Camera(C.Structure):
+    _fields_ = [("origin", C.c_float * 3), ("horizontal", C.c_float * 3), ("vertical", C.c_float * 3),
+                ("up_left", C.c_float * 3)]
+
+    @classmethod
+    def from12(cls, cam12):
+        a = [float(x) for x in np.asarray(cam12, dtype=np.float32).reshape(12)]
+        c = cls()
+        c.origin[:] = a[0:3]
+        c.horizontal[:] = a[3:6]
+        c.vertical[:] = a[6:9]
+        c.up_left[:] = a[9:12]
+        return c
+
+
+class Partition(C.Structure):
+    _fields_ = [("rank", C.c_int32), ("num_ranks", C.c_int32), ("strip_rows", C.c_int32)]
+
+
+class RenderParams(C.Structure):
+    _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("spp", C.c_int32), ("max_depth", C.c_int32),
+                ("part", Partition)]
+
+
+class Stats(C.Structure):
+    _fields_ = [("primary_rays", C.c_uint64), ("shadow_rays", C.c_uint64), ("hit_pixels", C.c_uint64),
+                ("occluded", C.c_uint64), ("kernel_ms", C.c_float)]
+
+    def as_dict(self):
+        return {"primary_rays": int(self.primary_rays), "shadow_rays": int(self.shadow_rays),
+                "hit_pixels": int(self.hit_pixels), "occluded": int(self.occluded), "kernel_ms": float(self.kernel_ms)}
+
+
+_libmrt = None
+_libhost = None
+
+
+def libmrt():
+    """Load libmrt.so.  Raises if it was not built (no fallback)."""
+    global _libmrt
+    if _libmrt is None:
+        if not os.path.exists(LIBMRT_PATH):
+            raise MrtError(f"{LIBMRT_PATH} is missing: build it with `make -C raytracing_amd/csrc` "
+                           "(or __graft_entry__.build()); there is no CPU fallback")
+        L = C.CDLL(LIBMRT_PATH)
+        L.mrt_device_count.argtypes = [C.POINTER(C.c_int)]
+        L.mrt_ctx_create.argtypes = [C.c_int, C.POINTER(C.c_void_p)]
+        L.mrt_ctx_destroy.argtypes = [C.c_void_p]
+        L.mrt_last_error.argtypes = [C.c_void_p]
+        L.mrt_last_error.restype = C.c_char_p
+        L.mrt_status_string.argtypes = [C.c_int]
+        L.mrt_status_string.restype = C.c_char_p
+        L.mrt_scene_upload.argtypes = [C.c_void_p, C.POINTER(SceneDesc)]
+        L.mrt_local_rows.argtypes = [C.c_int32, C.POINTER(Partition), _i32]
+        L.mrt_render.argtypes = [C.c_void_p, C.POINTER(Camera), C.POINTER(RenderParams), C.c_void_p, C.c_void_p,
+                                 C.c_void_p, C.POINTER(Stats)]
+        L.mrt_render_device.argtypes = [C.c_void_p, C.POINTER(Camera), C.POINTER(RenderParams), C.c_void_p,
+                                        C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.mrt_assemble_strips.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_int32, C.c_int32,
+                                          C.c_int32, C.c_int32, C.c_int32, C.c_void_p]
+        L.mrt_intersect.argtypes = [C.c_void_p, C.c_int, _f, _f, C.c_float, C.c_float, C.c_int64, _u8, _f, _f, _f]
+        _libmrt = L
+    return _libmrt
+
+
+def libhost():
+    """Load libmrt_host.so (C exports of the C++ host layer)."""
+    global _libhost
+    if _libhost is None:
+        if not os.path.exists(LIBHOST_PATH):
+            raise MrtError(f"{LIBHOST_PATH} is missing: build it with `make -C raytracing_amd/host`")
+        L = C.CDLL(LIBHOST_PATH)
+        L.rth_viewport.argtypes = [_f, _f, _f, C.c_float, C.c_float, _f]
+        L.rth_triangle_precompute.argtypes = [_f, C.c_int64, _f]
+        L.rth_directional_light_dir.argtypes = [_f, _f]
+        L.rth_default_scene_create.restype = C.c_void_p
+        L.rth_flat_scene_destroy.argtypes = [C.c_void_p]
+        L.rth_flat_scene_desc.argtypes = [C.c_void_p, C.POINTER(SceneDesc)]
+        L.rth_msmesh_offsets.argtypes = [C.c_float, C.c_float, _f]
+        _libhost = L
+    return _libhost
+
+
+def _fp(a):
+    return a.ctypes.data_as(_f)
+
+
+# ------------------------------------------------------------------ host-layer helpers
+
+def viewport(look_from, look_at, up, vfov_deg, aspect):
+    """rt::Viewport constructor -> 12 floats (origin, horizontal, vertical, up_left)."""
+    out = np.zeros(12, dtype=np.float32)
+    a = [np.asarray(v, dtype=np.float32) for v in (look_from, look_at, up)]
+    libhost().rth_viewport(_fp(a[0]), _fp(a[1]), _fp(a[2]), float(vfov_deg), float(aspect), _fp(out))
+    return out
+
+
+def default_viewport(aspect=2.0):
+    """config::make_viewport() of the reference (src/main.cu:34-41)."""
+    return viewport((0.0, 4.0, 6.0), (0.0, 0.0, -20.0), (0.0, 1.0, 0.0), 20.0, aspect)
+
+
+def triangle_precompute(verts):
+    """rt::Triangle constructor, batched.  verts [n,3,3] -> [16,n] streams."""
+    v = np.ascontiguousarray(verts, dtype=np.float32).reshape(-1, 9)
+    n = v.shape[0]
+    out = np.zeros((16, n), dtype=np.float32)
+    if n:
+        libhost().rth_triangle_precompute(_fp(v), n, _fp(out))
+    return out
+
+
+def directional_light_dir(d):
+    a = np.asarray(d, dtype=np.float32)
+    out = np.zeros(3, dtype=np.float32)
+    libhost().rth_directional_light_dir(_fp(a), _fp(out))
+    return out
+
+
+class FlatScene:
+    """SoA scene in the layout of mrt_scene_desc (numpy arrays kept alive here)."""
+
+    def __init__(self, mat_kind, mat_rgb, spheres, sphere_obj, tri16, tri_obj, light_kind, light_vec, light_rgb):
+        self.mat_kind = np.ascontiguousarray(mat_kind, dtype=np.uint8)
+        self.mat_rgb = np.ascontiguousarray(mat_rgb, dtype=np.float32).reshape(-1, 3)
+        sp = np.ascontiguousarray(spheres, dtype=np.float32).reshape(-1, 4)
+        self.sphere_cx = np.ascontiguousarray(sp[:, 0])
+        self.sphere_cy = np.ascontiguousarray(sp[:, 1])
+        self.sphere_cz = np.ascontiguousarray(sp[:, 2])
+        self.sphere_r = np.ascontiguousarray(sp[:, 3])
+        self.sphere_obj = np.ascontiguousarray(sphere_obj, dtype=np.int32)
+        self.tri = np.ascontiguousarray(tri16, dtype=np.float32).reshape(16, -1)
+        self.tri_obj = np.ascontiguousarray(tri_obj, dtype=np.int32)
+        self.light_kind = np.ascontiguousarray(light_kind, dtype=np.uint8)
+        self.light_vec = np.ascontiguousarray(light_vec, dtype=np.float32).reshape(-1, 3)
+        self.light_rgb = np.ascontiguousarray(light_rgb, dtype=np.float32).reshape(-1, 3)
+
+    @property
+    def num_objects(self):
+        return len(self.mat_kind)
+
+    @property
+    def num_spheres(self):
+        return len(self.sphere_obj)
+
+    @property
+    def num_triangles(self):
+        return len(self.tri_obj)
+
+    @property
+    def num_lights(self):
+        return len(self.light_kind)
+
+    def desc(self):
+        d = SceneDesc()
+        d.num_objects = self.num_objects
+        d.mat_kind = self.mat_kind.ctypes.data_as(_u8)
+        d.mat_rgb = _fp(self.mat_rgb)
+        d.num_spheres = self.num_spheres
+        d.sphere_cx, d.sphere_cy, d.sphere_cz, d.sphere_r = (_fp(self.sphere_cx), _fp(self.sphere_cy),
+                                                             _fp(self.sphere_cz), _fp(self.sphere_r))
+        d.sphere_obj = self.sphere_obj.ctypes.data_as(_i32)
+        d.num_triangles = self.num_triangles
+        d.tri = _fp(self.tri)
+        d.tri_obj = self.tri_obj.ctypes.data_as(_i32)
+        d.num_lights = self.num_lights
+        d.light_kind = self.light_kind.ctypes.data_as(_u8)
+        d.light_vec = _fp(self.light_vec)
+        d.light_rgb = _fp(self.light_rgb)
+        return d
+
+    @classmethod
+    def default(cls):
+        """The reference's hard-coded scene, built and flattened by the C++ host layer."""
+        H = libhost()
+        h = C.c_void_p(H.rth_default_scene_create())
+        try:
+            d = SceneDesc()
+            H.rth_flat_scene_desc(h, C.byref(d))
+            arr = lambda p, n, dt: np.ctypeslib.as_array(p, shape=(n,)).astype(dt, copy=True) if n else np.zeros(0, dt)
+            ns, nt, no, nl = d.num_spheres, d.num_triangles, d.num_objects, d.num_lights
+            spheres = np.stack([arr(d.sphere_cx, ns, np.float32), arr(d.sphere_cy, ns, np.float32),
+                                arr(d.sphere_cz, ns, np.float32), arr(d.sphere_r, ns, np.float32)], axis=1)
+            return cls(arr(d.mat_kind, no, np.uint8), arr(d.mat_rgb, no * 3, np.float32), spheres,
+                       arr(d.sphere_obj, ns, np.int32), arr(d.tri, nt * 16, np.float32), arr(d.tri_obj, nt, np.int32),
+                       arr(d.light_kind, nl, np.uint8), arr(d.light_vec, nl * 3, np.float32),
+                       arr(d.light_rgb, nl * 3, np.float32))
+        finally:
+            H.rth_flat_scene_destroy(h)
+
+
+# ------------------------------------------------------------------ GPU context
+
+def device_count():
+    n = C.c_int(0)
+    rc = libmrt().mrt_device_count(C.byref(n))
+    if rc != 0:
+        raise MrtError(f"mrt_device_count: {rc} {libmrt().mrt_last_error(None).decode()}")
+    return n.value
+
+
+def local_rows(height, rank=0, num_ranks=1, strip_rows=8):
+    p = Partition(rank, num_ranks, strip_rows)
+    r = C.c_int32(0)
+    rc = libmrt().mrt_local_rows(height, C.byref(p), C.byref(r))
+    if rc != 0:
+        raise MrtError(f"mrt_local_rows: {rc}")
+    return r.value
+
+
+def local_row_index(height, rank, num_ranks, strip_rows=8):
+    """Global row numbers of a rank's local rows, in local order (host mirror of the strip rule)."""
+    rows = []
+    nstrips = (height + strip_rows - 1) // strip_rows
+    for s in range(rank, nstrips, num_ranks):
+        rows.extend(range(s * strip_rows, min(height, (s + 1) * strip_rows)))
+    return np.asarray(rows, dtype=np.int64)
+
+
+class Context:
+    """One GPU (mrt_ctx)."""
+
+    def __init__(self, device=0):
+        self._L = libmrt()
+        h = C.c_void_p()
+        rc = self._L.mrt_ctx_create(int(device), C.byref(h))
+        if rc != 0:
+            raise MrtError(f"mrt_ctx_create({device}): {rc} {self._L.mrt_last_error(None).decode()}")
+        self._h = h
+        self.device = device
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.mrt_ctx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def _check(self, rc, what):
+        if rc != 0:
+            raise MrtError(f"{what}: {rc} ({self._L.mrt_status_string(rc).decode()}) "
+                           f"{self._L.mrt_last_error(self._h).decode()}")
+
+    def upload(self, flat):
+        d = flat.desc()
+        self._check(self._L.mrt_scene_upload(self._h, C.byref(d)), "mrt_scene_upload")
+
+    @staticmethod
+    def _params(W, H, spp, max_depth, rank, num_ranks, strip_rows):
+        p = RenderParams()
+        p.width, p.height, p.spp, p.max_depth = W, H, spp, max_depth
+        p.part = Partition(rank, num_ranks, strip_rows)
+        return p
+
+    def render(self, cam12, W, H, spp=1, max_depth=0, rank=0, num_ranks=1, strip_rows=8, want_stats=True):
+        """Blocking render into host arrays of the rank's local rows."""
+        rows = local_rows(H, rank, num_ranks, strip_rows)
+        rgb = np.zeros((rows, W, 3), dtype=np.float32)
+        ids = np.full((rows, W), -2, dtype=np.int32)
+        t = np.zeros((rows, W), dtype=np.float32)
+        cam = Camera.from12(cam12)
+        p = self._params(W, H, spp, max_depth, rank, num_ranks, strip_rows)
+        st = Stats()
+        rc = self._L.mrt_render(self._h, C.byref(cam), C.byref(p), rgb.ctypes.data, ids.ctypes.data, t.ctypes.data,
+                                C.byref(st) if want_stats else None)
+        self._check(rc, "mrt_render")
+        return {"rgb": rgb, "id": ids, "t": t, "stats": st.as_dict() if want_stats else None}
+
+    def render_device(self, cam12, W, H, rgb_ptr, id_ptr=None, t_ptr=None, stats_ptr=None, stream=None, spp=1,
+                      max_depth=0, rank=0, num_ranks=1, strip_rows=8):
+        """Asynchronous render into device buffers (raw pointers, e.g. torch tensor.data_ptr())."""
+        cam = Camera.from12(cam12)
+        p = self._params(W, H, spp, max_depth, rank, num_ranks, strip_rows)
+        rc = self._L.mrt_render_device(self._h, C.byref(cam), C.byref(p), C.c_void_p(rgb_ptr),
+                                       C.c_void_p(id_ptr) if id_ptr else None, C.c_void_p(t_ptr) if t_ptr else None,
+                                       C.c_void_p(stats_ptr) if stats_ptr else None,
+                                       C.c_void_p(stream) if stream else None)
+        self._check(rc, "mrt_render_device")
+
+    def assemble_strips(self, gathered_ptr, rank_stride_elems, frame_ptr, W, H, elem_dwords, num_ranks, strip_rows=8,
+                        stream=None):
+        rc = self._L.mrt_assemble_strips(self._h, C.c_void_p(gathered_ptr), rank_stride_elems, C.c_void_p(frame_ptr),
+                                         W, H, elem_dwords, num_ranks, strip_rows,
+                                         C.c_void_p(stream) if stream else None)
+        self._check(rc, "mrt_assemble_strips")
+
+    def intersect(self, prim_kind, prim, rays, tmin, tmax):
+        """Batched hit test of one primitive against rays [n,6] (origin, direction)."""
+        prim = np.ascontiguousarray(prim, dtype=np.float32).reshape(-1)
+        rays = np.ascontiguousarray(rays, dtype=np.float32).reshape(-1, 6)
+        n = rays.shape[0]
+        hit = np.zeros(n, dtype=np.uint8)
+        t = np.zeros(n, dtype=np.float32)
+        point = np.zeros((n, 3), dtype=np.float32)
+        normal = np.zeros((n, 3), dtype=np.float32)
+        rc = self._L.mrt_intersect(self._h, int(prim_kind), _fp(prim), _fp(rays), float(tmin), float(tmax), n,
+                                   hit.ctypes.data_as(_u8), _fp(t), _fp(point), _fp(normal))
+        self._check(rc, "mrt_intersect")
+        return hit.astype(bool), t, point, normal

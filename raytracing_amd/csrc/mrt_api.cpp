@@ -1,0 +1,353 @@
+// mrt_api.cpp -- C-ABI of libmrt.so (declared in include/mrt.h).
+//
+// Thin layer: owns one GPU context (device, stream, scene SoA buffers in HBM,
+// output staging buffers), validates shapes on the host before any launch, and
+// turns HIP failures into status codes + an error string.  It never exits and
+// never throws; the print-and-exit convention of the reference's
+// src/check_error.cu:7-15 is kept by the C++ host layer (checkRtErrors).
+
+#include "mrt.h"
+#include "mrt_internal.h"
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+struct mrt_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  std::string err;
+
+  // scene in HBM (one allocation, SoA streams carved out of it)
+  void *scene_mem = nullptr;
+  size_t scene_bytes = 0;
+  mrt::DevScene sc{};
+  bool have_scene = false;
+
+  // output staging for the blocking host-buffer entry point
+  void *out_mem = nullptr;
+  size_t out_bytes = 0;
+  unsigned long long *stats_dev = nullptr;
+};
+
+static thread_local std::string g_create_err;
+
+static int fail(mrt_ctx *ctx, int code, const std::string &msg)
+{
+  if (ctx) ctx->err = msg; else g_create_err = msg;
+  return code;
+}
+
+static int hip_fail(mrt_ctx *ctx, hipError_t e, const char *what)
+{
+  char buf[256];
+  std::snprintf(buf, sizeof buf, "HIP error: %d (%s) in %s", (int)e, hipGetErrorString(e), what);
+  return fail(ctx, MRT_ERR_HIP, buf);
+}
+
+#define HIP_TRY(ctx, expr)                                   \
+  do {                                                       \
+    hipError_t e_ = (expr);                                  \
+    if (e_ != hipSuccess) return hip_fail((ctx), e_, #expr); \
+  } while (0)
+
+extern "C" {
+
+const char *mrt_status_string(int status)
+{
+  switch (status) {
+  case MRT_OK: return "ok";
+  case MRT_ERR_INVALID: return "invalid argument";
+  case MRT_ERR_HIP: return "HIP runtime error";
+  case MRT_ERR_NO_SCENE: return "no scene uploaded";
+  case MRT_ERR_NO_DEVICE: return "no usable GPU";
+  case MRT_ERR_TOO_LARGE: return "size beyond limit";
+  default: return "unknown status";
+  }
+}
+
+const char *mrt_last_error(const mrt_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_err.c_str(); }
+
+int mrt_device_count(int *count)
+{
+  if (!count) return MRT_ERR_INVALID;
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess) { *count = 0; return hip_fail(nullptr, e, "hipGetDeviceCount"); }
+  *count = n;
+  return MRT_OK;
+}
+
+int mrt_ctx_create(int device, mrt_ctx **out)
+{
+  if (!out) return MRT_ERR_INVALID;
+  *out = nullptr;
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess || n <= 0) return fail(nullptr, MRT_ERR_NO_DEVICE, "no HIP device visible");
+  if (device < 0 || device >= n) return fail(nullptr, MRT_ERR_INVALID, "device index out of range");
+  mrt_ctx *ctx = new (std::nothrow) mrt_ctx();
+  if (!ctx) return fail(nullptr, MRT_ERR_INVALID, "out of host memory");
+  ctx->device = device;
+  auto bail = [&](hipError_t err, const char *what) {
+    int rc = hip_fail(nullptr, err, what);
+    mrt_ctx_destroy(ctx);
+    return rc;
+  };
+  if ((e = hipSetDevice(device)) != hipSuccess) return bail(e, "hipSetDevice");
+  if ((e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)) != hipSuccess) return bail(e, "hipStreamCreate");
+  if ((e = hipEventCreate(&ctx->ev0)) != hipSuccess) return bail(e, "hipEventCreate");
+  if ((e = hipEventCreate(&ctx->ev1)) != hipSuccess) return bail(e, "hipEventCreate");
+  if ((e = hipMalloc((void **)&ctx->stats_dev, 4 * sizeof(unsigned long long))) != hipSuccess) return bail(e, "hipMalloc");
+  *out = ctx;
+  return MRT_OK;
+}
+
+int mrt_ctx_destroy(mrt_ctx *ctx)
+{
+  if (!ctx) return MRT_OK;
+  (void)hipSetDevice(ctx->device);
+  if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+  if (ctx->scene_mem) (void)hipFree(ctx->scene_mem);
+  if (ctx->out_mem) (void)hipFree(ctx->out_mem);
+  if (ctx->stats_dev) (void)hipFree(ctx->stats_dev);
+  if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
+  if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+  if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+  delete ctx;
+  return MRT_OK;
+}
+
+static size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+int mrt_scene_upload(mrt_ctx *ctx, const mrt_scene_desc *s)
+{
+  if (!ctx || !s) return MRT_ERR_INVALID;
+  if (s->num_objects < 0 || s->num_spheres < 0 || s->num_triangles < 0 || s->num_lights < 0)
+    return fail(ctx, MRT_ERR_INVALID, "negative count in scene");
+  if (s->num_objects > 0 && (!s->mat_kind || !s->mat_rgb)) return fail(ctx, MRT_ERR_INVALID, "missing material arrays");
+  if (s->num_spheres > 0 && (!s->sphere_cx || !s->sphere_cy || !s->sphere_cz || !s->sphere_r || !s->sphere_obj))
+    return fail(ctx, MRT_ERR_INVALID, "missing sphere arrays");
+  if (s->num_triangles > 0 && (!s->tri || !s->tri_obj)) return fail(ctx, MRT_ERR_INVALID, "missing triangle arrays");
+  if (s->num_lights > 0 && (!s->light_kind || !s->light_vec || !s->light_rgb))
+    return fail(ctx, MRT_ERR_INVALID, "missing light arrays");
+  if ((int64_t)s->num_spheres + s->num_triangles > s->num_objects)
+    return fail(ctx, MRT_ERR_INVALID, "more primitives than objects");
+  // object numbers: in range, strictly ascending per type (closest-hit tie rule relies on it)
+  for (int t = 0; t < 2; ++t) {
+    const int32_t *o = t ? s->tri_obj : s->sphere_obj;
+    const int n = t ? s->num_triangles : s->num_spheres;
+    for (int i = 0; i < n; ++i) {
+      if (o[i] < 0 || o[i] >= s->num_objects) return fail(ctx, MRT_ERR_INVALID, "primitive object number out of range");
+      if (i && o[i] <= o[i - 1]) return fail(ctx, MRT_ERR_INVALID, "primitive object numbers must ascend");
+    }
+  }
+  for (int i = 0; i < s->num_objects; ++i)
+    if (s->mat_kind[i] > MRT_MAT_METALLIC) return fail(ctx, MRT_ERR_INVALID, "unknown material kind");
+  for (int i = 0; i < s->num_lights; ++i)
+    if (s->light_kind[i] > MRT_LIGHT_POINT) return fail(ctx, MRT_ERR_INVALID, "unknown light kind");
+
+  const size_t ns = s->num_spheres, nt = s->num_triangles, no = s->num_objects, nl = s->num_lights;
+  // carve one host image, one device allocation, one copy
+  size_t off = 0;
+  auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
+  const size_t o_cx = take(ns * 4), o_cy = take(ns * 4), o_cz = take(ns * 4), o_r = take(ns * 4), o_so = take(ns * 4);
+  const size_t o_tri = take(nt * 16 * 4), o_to = take(nt * 4);
+  const size_t o_mk = take(no), o_mrgb = take(no * 12);
+  const size_t o_lk = take(nl), o_lv = take(nl * 12), o_lc = take(nl * 12);
+  const size_t total = off ? off : 256;
+
+  std::vector<unsigned char> img;
+  try { img.assign(total, 0); } catch (...) { return fail(ctx, MRT_ERR_INVALID, "out of host memory"); }
+  auto put = [&](size_t o, const void *src, size_t bytes) { if (bytes) std::memcpy(img.data() + o, src, bytes); };
+  put(o_cx, s->sphere_cx, ns * 4); put(o_cy, s->sphere_cy, ns * 4); put(o_cz, s->sphere_cz, ns * 4);
+  put(o_r, s->sphere_r, ns * 4);   put(o_so, s->sphere_obj, ns * 4);
+  put(o_tri, s->tri, nt * 64);     put(o_to, s->tri_obj, nt * 4);
+  put(o_mk, s->mat_kind, no);      put(o_mrgb, s->mat_rgb, no * 12);
+  put(o_lk, s->light_kind, nl);    put(o_lv, s->light_vec, nl * 12); put(o_lc, s->light_rgb, nl * 12);
+
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  if (ctx->scene_bytes < total) {
+    if (ctx->scene_mem) { HIP_TRY(ctx, hipFree(ctx->scene_mem)); ctx->scene_mem = nullptr; ctx->scene_bytes = 0; }
+    HIP_TRY(ctx, hipMalloc(&ctx->scene_mem, total));
+    ctx->scene_bytes = total;
+  }
+  ctx->have_scene = false;
+  HIP_TRY(ctx, hipMemcpy(ctx->scene_mem, img.data(), total, hipMemcpyHostToDevice));
+
+  unsigned char *b = (unsigned char *)ctx->scene_mem;
+  mrt::DevScene &d = ctx->sc;
+  d.sph_cx = (const float *)(b + o_cx); d.sph_cy = (const float *)(b + o_cy); d.sph_cz = (const float *)(b + o_cz);
+  d.sph_r = (const float *)(b + o_r);   d.sph_obj = (const int32_t *)(b + o_so); d.ns = (int32_t)ns;
+  d.tri = (const float *)(b + o_tri);   d.tri_obj = (const int32_t *)(b + o_to); d.nt = (int32_t)nt;
+  d.mat_kind = b + o_mk; d.mat_rgb = (const float *)(b + o_mrgb); d.nobj = (int32_t)no;
+  d.light_kind = b + o_lk; d.light_vec = (const float *)(b + o_lv); d.light_rgb = (const float *)(b + o_lc);
+  d.nl = (int32_t)nl;
+  ctx->have_scene = true;
+  return MRT_OK;
+}
+
+static bool partition_ok(const mrt_partition &p)
+{
+  return p.num_ranks >= 1 && p.rank >= 0 && p.rank < p.num_ranks && p.strip_rows >= 8 && (p.strip_rows % 8) == 0;
+}
+
+static int local_rows_of(int H, const mrt_partition &p)
+{
+  const int nstrips = (H + p.strip_rows - 1) / p.strip_rows;
+  int rows = 0;
+  for (int s = p.rank; s < nstrips; s += p.num_ranks) {
+    const int r0 = s * p.strip_rows;
+    rows += (r0 + p.strip_rows <= H) ? p.strip_rows : (H - r0);
+  }
+  return rows;
+}
+
+int mrt_local_rows(int32_t height, const mrt_partition *part, int32_t *rows)
+{
+  if (!part || !rows || height < 0 || !partition_ok(*part)) return MRT_ERR_INVALID;
+  *rows = local_rows_of(height, *part);
+  return MRT_OK;
+}
+
+static int fill_args(mrt_ctx *ctx, const mrt_camera *cam, const mrt_render_params *p, mrt::RenderArgs &A)
+{
+  if (!ctx || !cam || !p) return MRT_ERR_INVALID;
+  if (!ctx->have_scene) return fail(ctx, MRT_ERR_NO_SCENE, "mrt_render before mrt_scene_upload");
+  if (p->width <= 0 || p->height <= 0) return fail(ctx, MRT_ERR_INVALID, "non-positive frame size");
+  if (p->width > 65536 || p->height > 65536) return fail(ctx, MRT_ERR_TOO_LARGE, "frame larger than 65536 in a dimension");
+  if (p->spp != 1 && p->spp != 121) return fail(ctx, MRT_ERR_INVALID, "spp must be 1 or 121");
+  if (p->max_depth != 0) return fail(ctx, MRT_ERR_INVALID, "only max_depth 0 (primary + shadow) is implemented");
+  if (!partition_ok(p->part)) return fail(ctx, MRT_ERR_INVALID, "bad strip partition");
+  std::memset(&A, 0, sizeof A);
+  A.sc = ctx->sc;
+  A.cam.ox = cam->origin[0]; A.cam.oy = cam->origin[1]; A.cam.oz = cam->origin[2];
+  A.cam.hx = cam->horizontal[0]; A.cam.hy = cam->horizontal[1]; A.cam.hz = cam->horizontal[2];
+  A.cam.vx = cam->vertical[0]; A.cam.vy = cam->vertical[1]; A.cam.vz = cam->vertical[2];
+  A.cam.ux = cam->up_left[0]; A.cam.uy = cam->up_left[1]; A.cam.uz = cam->up_left[2];
+  A.W = p->width; A.H = p->height;
+  A.rank = p->part.rank; A.nranks = p->part.num_ranks; A.strip_rows = p->part.strip_rows;
+  A.local_rows = local_rows_of(p->height, p->part);
+  A.spp = p->spp;
+  return MRT_OK;
+}
+
+int mrt_render_device(mrt_ctx *ctx, const mrt_camera *cam, const mrt_render_params *params, void *rgb_dev,
+                      void *id_dev, void *t_dev, void *stats_dev, void *stream)
+{
+  mrt::RenderArgs A;
+  int rc = fill_args(ctx, cam, params, A);
+  if (rc != MRT_OK) return rc;
+  if (!rgb_dev) return fail(ctx, MRT_ERR_INVALID, "rgb buffer is required");
+  A.rgb = (float *)rgb_dev; A.id = (int32_t *)id_dev; A.t = (float *)t_dev;
+  A.stats = (unsigned long long *)stats_dev;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
+  if (A.stats) HIP_TRY(ctx, hipMemsetAsync(A.stats, 0, 4 * sizeof(unsigned long long), st));
+  HIP_TRY(ctx, mrt::launch_render(A, st));
+  return MRT_OK;
+}
+
+int mrt_render(mrt_ctx *ctx, const mrt_camera *cam, const mrt_render_params *params, float *rgb, int32_t *id, float *t,
+               mrt_stats *stats)
+{
+  mrt::RenderArgs A;
+  int rc = fill_args(ctx, cam, params, A);
+  if (rc != MRT_OK) return rc;
+  if (!rgb) return fail(ctx, MRT_ERR_INVALID, "rgb buffer is required");
+  const size_t npix = (size_t)A.local_rows * A.W;
+  const size_t need = npix * 20 + 256;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  if (ctx->out_bytes < need) {
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->out_mem) { HIP_TRY(ctx, hipFree(ctx->out_mem)); ctx->out_mem = nullptr; ctx->out_bytes = 0; }
+    HIP_TRY(ctx, hipMalloc(&ctx->out_mem, need));
+    ctx->out_bytes = need;
+  }
+  A.rgb = (float *)ctx->out_mem;
+  A.id = (int32_t *)((char *)ctx->out_mem + npix * 12);
+  A.t = (float *)((char *)ctx->out_mem + npix * 16);
+  A.stats = stats ? ctx->stats_dev : nullptr;
+  if (A.stats) HIP_TRY(ctx, hipMemsetAsync(A.stats, 0, 4 * sizeof(unsigned long long), ctx->stream));
+  HIP_TRY(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+  HIP_TRY(ctx, mrt::launch_render(A, ctx->stream));
+  HIP_TRY(ctx, hipEventRecord(ctx->ev1, ctx->stream));
+  if (npix) {
+    HIP_TRY(ctx, hipMemcpyAsync(rgb, A.rgb, npix * 12, hipMemcpyDeviceToHost, ctx->stream));
+    if (id) HIP_TRY(ctx, hipMemcpyAsync(id, A.id, npix * 4, hipMemcpyDeviceToHost, ctx->stream));
+    if (t) HIP_TRY(ctx, hipMemcpyAsync(t, A.t, npix * 4, hipMemcpyDeviceToHost, ctx->stream));
+  }
+  unsigned long long h[4] = {0, 0, 0, 0};
+  if (stats) HIP_TRY(ctx, hipMemcpyAsync(h, ctx->stats_dev, sizeof h, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  if (stats) {
+    stats->primary_rays = h[0]; stats->shadow_rays = h[1]; stats->hit_pixels = h[2]; stats->occluded = h[3];
+    float ms = 0.0f;
+    HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+    stats->kernel_ms = ms;
+  }
+  return MRT_OK;
+}
+
+int mrt_assemble_strips(mrt_ctx *ctx, const void *gathered_dev, size_t rank_stride_elems, void *frame_dev, int32_t width,
+                        int32_t height, int32_t elem_dwords, int32_t num_ranks, int32_t strip_rows, void *stream)
+{
+  if (!ctx || !gathered_dev || !frame_dev) return MRT_ERR_INVALID;
+  if (width <= 0 || height <= 0 || elem_dwords <= 0 || num_ranks <= 0 || strip_rows <= 0)
+    return fail(ctx, MRT_ERR_INVALID, "bad assemble shape");
+  mrt_partition p0{0, num_ranks, strip_rows};
+  if (!partition_ok(p0)) return fail(ctx, MRT_ERR_INVALID, "bad strip partition");
+  // rank 0 holds the most rows; every rank's slab must fit in the stride
+  if ((size_t)local_rows_of(height, p0) * width * elem_dwords > rank_stride_elems)
+    return fail(ctx, MRT_ERR_INVALID, "rank stride smaller than a rank's strip buffer");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
+  HIP_TRY(ctx, mrt::launch_assemble((const uint32_t *)gathered_dev, rank_stride_elems, (uint32_t *)frame_dev, width,
+                                    height, elem_dwords, num_ranks, strip_rows, st));
+  return MRT_OK;
+}
+
+int mrt_intersect(mrt_ctx *ctx, int prim_kind, const float *prim, const float *rays, float tmin, float tmax, int64_t n,
+                  uint8_t *hit, float *t, float *point, float *normal)
+{
+  if (!ctx || !prim || n < 0 || (n > 0 && (!rays || !hit || !t || !point || !normal))) return MRT_ERR_INVALID;
+  if (prim_kind != MRT_GEOM_SPHERE && prim_kind != MRT_GEOM_PLANE && prim_kind != MRT_GEOM_TRIANGLE)
+    return fail(ctx, MRT_ERR_INVALID, "unknown primitive kind");
+  if (n == 0) return MRT_OK;
+  if (n > (int64_t)1 << 28) return fail(ctx, MRT_ERR_TOO_LARGE, "more than 2^28 rays in one call");
+  const size_t nprim = (prim_kind == MRT_GEOM_TRIANGLE ? 16 : 4) * sizeof(float);
+  const size_t b_rays = (size_t)n * 24, b_hit = align_up((size_t)n, 256), b_t = (size_t)n * 4, b_v = (size_t)n * 12;
+  const size_t total = 256 + b_rays + b_hit + b_t + 2 * b_v;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  char *mem = nullptr;
+  HIP_TRY(ctx, hipMalloc((void **)&mem, total));
+  float *d_prim = (float *)mem;
+  float *d_rays = (float *)(mem + 256);
+  float *d_t = (float *)(mem + 256 + b_rays);
+  float *d_point = (float *)(mem + 256 + b_rays + b_t);
+  float *d_normal = (float *)(mem + 256 + b_rays + b_t + b_v);
+  uint8_t *d_hit = (uint8_t *)(mem + 256 + b_rays + b_t + 2 * b_v);
+  int rc = MRT_OK;
+  hipError_t e;
+  do {
+    if ((e = hipMemcpyAsync(d_prim, prim, nprim, hipMemcpyHostToDevice, ctx->stream)) != hipSuccess) break;
+    if ((e = hipMemcpyAsync(d_rays, rays, b_rays, hipMemcpyHostToDevice, ctx->stream)) != hipSuccess) break;
+    if ((e = mrt::launch_intersect(prim_kind, d_prim, d_rays, tmin, tmax, n, d_hit, d_t, d_point, d_normal,
+                                   ctx->stream)) != hipSuccess) break;
+    if ((e = hipMemcpyAsync(hit, d_hit, (size_t)n, hipMemcpyDeviceToHost, ctx->stream)) != hipSuccess) break;
+    if ((e = hipMemcpyAsync(t, d_t, b_t, hipMemcpyDeviceToHost, ctx->stream)) != hipSuccess) break;
+    if ((e = hipMemcpyAsync(point, d_point, b_v, hipMemcpyDeviceToHost, ctx->stream)) != hipSuccess) break;
+    if ((e = hipMemcpyAsync(normal, d_normal, b_v, hipMemcpyDeviceToHost, ctx->stream)) != hipSuccess) break;
+    e = hipStreamSynchronize(ctx->stream);
+  } while (0);
+  if (e != hipSuccess) rc = hip_fail(ctx, e, "mrt_intersect");
+  (void)hipFree(mem);
+  return rc;
+}
+
+} // extern "C"

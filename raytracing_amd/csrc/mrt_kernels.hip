@@ -1,0 +1,604 @@
+// mrt_kernels.hip -- hand-written gfx950 kernels of the render hot path.
+//
+// Build with -ffp-contract=off and WITHOUT fast-math: every expression below has the
+// operation order of the CPU oracle (oracle/rt_oracle.c), which is the order of the
+// reference's Eigen expressions.  IEEE '/' and sqrtf (hipcc's default correctly
+// rounded expansions) are part of the contract.
+//
+// Mapping (DESIGN.md "Kernel"):
+//   workgroup = 256 threads = 4 wave64;  a wave owns an 8-row x (8*P)-column pixel
+//   tile: lane = ty*8 + tx holds the P adjacent pixels (tx*P .. tx*P+P-1, ty).  The
+//   primitive under test is the SAME for all 64 lanes, so it is read from LDS as a
+//   broadcast (one ds_read_b128 per 16 bytes of primitive) and reused for P rays.
+//   Scene SoA streams in HBM are transposed into float4 records while they are
+//   staged into LDS; ray-invariant terms of the primary rays (which share the
+//   camera origin) are folded into the record during staging:
+//     sphere   primary record: (o-c).xyz, (o-c).(o-c) - r*r        shadow record: c.xyz, r*r
+//     triangle record: pn.xyz,kp | n0.xyz,k0 | n1.xyz,k1 | n2.xyz,k2   + primary num = kp - o.pn
+//   These are the same fp32 operations the reference performs per test, done once.
+
+#include "mrt_internal.h"
+
+namespace mrt {
+
+#define MRT_INF __builtin_inff()
+
+__device__ __forceinline__ float dot3(float ax, float ay, float az, float bx, float by, float bz)
+{
+  return ax * bx + (ay * by + az * bz);
+}
+
+// core/interval.cuh:28-29
+__device__ __forceinline__ bool contains(float lo, float hi, float f) { return (lo <= f) && (f <= hi); }
+
+// v.normalized(): z = v.v; z > 0 ? v / sqrt(z) : v
+__device__ __forceinline__ void normalize3(float &x, float &y, float &z)
+{
+  float n2 = dot3(x, y, z, x, y, z);
+  if (n2 > 0.0f) {
+    float n = sqrtf(n2);
+    x = x / n; y = y / n; z = z / n;
+  }
+}
+
+// Exact tail of Sphere::hit (core/sphere.cuh:37-69) once a, b and the discriminant are known.
+__device__ __forceinline__ bool sphere_roots(float a, float b, float disc, float lo, float hi, float &t_out)
+{
+  if (disc > 0.0f) {
+    float sq = sqrtf(disc);
+    float t = (-b - sq) / a;
+    if (contains(lo, hi, t)) { t_out = t; return true; }
+    t = (-b + sq) / a;
+    if (contains(lo, hi, t)) { t_out = t; return true; }
+  } else if (disc == 0.0f) {
+    float t = (-b) / a;
+    if (contains(lo, hi, t)) { t_out = t; return true; }
+  }
+  return false;
+}
+
+// ------------------------------------------------------------------------------------------
+// LDS staging.  lds4 is the dynamic LDS viewed as float4.
+// Layout:  [0, s_cap)            sphere primary records
+//          [s_cap, 2 s_cap)      sphere shadow records
+//          [2 s_cap, +4 t_cap)   triangle records (4 float4 each)
+//          then t_cap floats     primary numerators kp - o.pn
+// ------------------------------------------------------------------------------------------
+
+struct LdsPlan {
+  float4 *sphP, *sphS, *tri;
+  float *triNum;
+};
+
+__device__ __forceinline__ LdsPlan lds_plan(float4 *base, int s_cap, int t_cap)
+{
+  LdsPlan p;
+  p.sphP = base;
+  p.sphS = base + s_cap;
+  p.tri = base + 2 * s_cap;
+  p.triNum = reinterpret_cast<float *>(base + 2 * s_cap + 4 * t_cap);
+  return p;
+}
+
+// which: bit0 primary records, bit1 shadow records
+__device__ __forceinline__ void stage_spheres(const DevScene &sc, const DevCamera &cam, const LdsPlan &L, int begin,
+                                              int count, int which)
+{
+  for (int i = threadIdx.x; i < count; i += blockDim.x) {
+    int g = begin + i;
+    float cx = sc.sph_cx[g], cy = sc.sph_cy[g], cz = sc.sph_cz[g], r = sc.sph_r[g];
+    float rr = r * r;
+    if (which & 1) {
+      float ocx = cam.ox - cx, ocy = cam.oy - cy, ocz = cam.oz - cz;
+      float c = dot3(ocx, ocy, ocz, ocx, ocy, ocz) - rr;
+      L.sphP[i] = make_float4(ocx, ocy, ocz, c);
+    }
+    if (which & 2) L.sphS[i] = make_float4(cx, cy, cz, rr);
+  }
+}
+
+__device__ __forceinline__ void stage_triangles(const DevScene &sc, const DevCamera &cam, const LdsPlan &L, int begin,
+                                                int count)
+{
+  const int nt = sc.nt;
+  for (int i = threadIdx.x; i < count; i += blockDim.x) {
+    const float *p = sc.tri + begin + i;
+    float4 q0 = make_float4(p[0], p[nt], p[2 * nt], p[3 * nt]);
+    float4 q1 = make_float4(p[4 * nt], p[5 * nt], p[6 * nt], p[7 * nt]);
+    float4 q2 = make_float4(p[8 * nt], p[9 * nt], p[10 * nt], p[11 * nt]);
+    float4 q3 = make_float4(p[12 * nt], p[13 * nt], p[14 * nt], p[15 * nt]);
+    L.tri[4 * i + 0] = q0;
+    L.tri[4 * i + 1] = q1;
+    L.tri[4 * i + 2] = q2;
+    L.tri[4 * i + 3] = q3;
+    L.triNum[i] = q0.w - dot3(cam.ox, cam.oy, cam.oz, q0.x, q0.y, q0.z);
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// render kernel
+// ------------------------------------------------------------------------------------------
+
+template <int P>
+__global__ __launch_bounds__(256) void render_kernel(RenderArgs A)
+{
+  extern __shared__ float4 lds4[];
+  const DevScene &sc = A.sc;
+  const DevCamera &cam = A.cam;
+  const LdsPlan L = lds_plan(lds4, A.s_cap, A.t_cap);
+
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int tx = lane & 7, ty = lane >> 3;
+  const int col0 = (blockIdx.x * 4 + wave) * (8 * P) + tx * P;
+  const int lrow = blockIdx.y * 8 + ty;
+  const int strip = lrow / A.strip_rows;
+  const int grow = (strip * A.nranks + A.rank) * A.strip_rows + (lrow - strip * A.strip_rows);
+  const bool row_ok = (lrow < A.local_rows) && (grow < A.H);
+
+  const int ns = sc.ns, nt = sc.nt;
+
+  if (A.resident) {
+    stage_spheres(sc, cam, L, 0, ns, 3);
+    stage_triangles(sc, cam, L, 0, nt);
+    __syncthreads();
+  }
+
+  bool valid[P];
+  float u[P];
+#pragma unroll
+  for (int p = 0; p < P; ++p) {
+    int col = col0 + p;
+    valid[p] = row_ok && (col < A.W);
+    u[p] = float(col) / float(A.W);     // src/main.cu:136
+  }
+  const float v = float(grow) / float(A.H); // src/main.cu:137
+
+  float accr[P], accg[P], accb[P];
+  int out_id[P];
+  float out_t[P];
+#pragma unroll
+  for (int p = 0; p < P; ++p) { accr[p] = 0.0f; accg[p] = 0.0f; accb[p] = 0.0f; out_id[p] = -1; out_t[p] = MRT_INF; }
+
+  unsigned int n_shadow = 0, n_hit = 0, n_occl = 0;
+
+  const int nsamp = A.spp;
+  const float DIVW = 13.0f, DIVH = 13.0f; // MultisampleMesh::WIDTH/HEIGHT + 2
+
+  for (int sidx = 0; sidx < nsamp; ++sidx) {
+    // sample offsets: pipeline/multisample_mesh.cuh:23-30 (zero offset in 1-spp mode)
+    float offx = 0.0f, offy = 0.0f;
+    if (nsamp > 1) {
+      int r = sidx / 11, c = sidx - r * 11;
+      offy = (-1.0f + 2.0f * float(r + 1) / DIVH) / float(A.H);
+      offx = (-1.0f + 2.0f * float(c + 1) / DIVW) / float(A.W);
+    }
+
+    // ---- primary rays: pipeline/viewport.cuh:30-34 ----
+    float dx[P], dy[P], dz[P], aa[P];
+    float best_t[P];
+    int best_obj[P], best_prim[P];
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+      float su = u[p], sv = v;
+      if (nsamp > 1) { su = u[p] + offx; sv = v + offy; }
+      dx[p] = ((cam.ux + su * cam.hx) + sv * cam.vx) - cam.ox;
+      dy[p] = ((cam.uy + su * cam.hy) + sv * cam.vy) - cam.oy;
+      dz[p] = ((cam.uz + su * cam.hz) + sv * cam.vz) - cam.oz;
+      aa[p] = dot3(dx[p], dy[p], dz[p], dx[p], dy[p], dz[p]);
+      best_t[p] = MRT_INF;
+      best_obj[p] = 0x7fffffff;
+      best_prim[p] = -1;
+    }
+
+    // ---- closest hit over spheres (src/main.cu:60-77 + core/sphere.cuh:32-73), interval [0.01, inf] ----
+    for (int c0 = 0; c0 < ns; c0 += A.s_cap) {
+      const int cnt = min(A.s_cap, ns - c0);
+      if (!A.resident) {
+        __syncthreads();
+        stage_spheres(sc, cam, L, c0, cnt, 1);
+        __syncthreads();
+      }
+      for (int j = 0; j < cnt; ++j) {
+        const float4 s = L.sphP[j]; // oc.xyz, oc.oc - r*r
+        float b[P], disc[P];
+        bool cand = false;
+#pragma unroll
+        for (int p = 0; p < P; ++p) {
+          b[p] = dot3(s.x, s.y, s.z, dx[p], dy[p], dz[p]);
+          disc[p] = b[p] * b[p] - aa[p] * s.w;
+          cand |= (disc[p] >= 0.0f);
+        }
+        if (cand) {
+          const int obj = sc.sph_obj[c0 + j];
+#pragma unroll
+          for (int p = 0; p < P; ++p) {
+            if (disc[p] >= 0.0f) {
+              float t;
+              if (sphere_roots(aa[p], b[p], disc[p], 0.01f, MRT_INF, t)) {
+                if (t < best_t[p] || (t == best_t[p] && t < MRT_INF && obj < best_obj[p])) {
+                  best_t[p] = t; best_obj[p] = obj; best_prim[p] = c0 + j;
+                }
+              }
+            }
+          }
+        }
+      }
+    }
+
+    // ---- closest hit over triangles (core/triangle.cuh:77-103) ----
+    for (int c0 = 0; c0 < nt; c0 += A.t_cap) {
+      const int cnt = min(A.t_cap, nt - c0);
+      if (!A.resident) {
+        __syncthreads();
+        stage_triangles(sc, cam, L, c0, cnt);
+        __syncthreads();
+      }
+      for (int j = 0; j < cnt; ++j) {
+        const float4 q0 = L.tri[4 * j + 0], q1 = L.tri[4 * j + 1], q2 = L.tri[4 * j + 2], q3 = L.tri[4 * j + 3];
+        const float num = L.triNum[j];
+        float t[P];
+        bool hit[P];
+        bool any = false;
+#pragma unroll
+        for (int p = 0; p < P; ++p) {
+          float rdn = dot3(dx[p], dy[p], dz[p], q0.x, q0.y, q0.z);
+          t[p] = num / rdn;
+          float px = cam.ox + t[p] * dx[p], py = cam.oy + t[p] * dy[p], pz = cam.oz + t[p] * dz[p];
+          float e0 = dot3(q1.x, q1.y, q1.z, px, py, pz) - q1.w;
+          float e1 = dot3(q2.x, q2.y, q2.z, px, py, pz) - q2.w;
+          float e2 = dot3(q3.x, q3.y, q3.z, px, py, pz) - q3.w;
+          hit[p] = (rdn != 0.0f) & (e0 > -1e-6f) & (e1 > -1e-6f) & (e2 > -1e-6f) & (0.01f <= t[p]) & (t[p] <= MRT_INF);
+          any |= hit[p];
+        }
+        if (any) {
+          const int obj = sc.tri_obj[c0 + j];
+#pragma unroll
+          for (int p = 0; p < P; ++p) {
+            if (hit[p] && (t[p] < best_t[p] || (t[p] == best_t[p] && t[p] < MRT_INF && obj < best_obj[p]))) {
+              best_t[p] = t[p]; best_obj[p] = obj; best_prim[p] = ns + c0 + j;
+            }
+          }
+        }
+      }
+    }
+
+    // ---- hit record of the winner: point, normal (core/sphere.cuh:45-47, core/triangle.cuh:96-97) ----
+    bool have_hit[P];
+    float hpx[P], hpy[P], hpz[P], hnx[P], hny[P], hnz[P];
+    bool any_hit = false;
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+      have_hit[p] = best_prim[p] >= 0;
+      hpx[p] = hpy[p] = hpz[p] = 0.0f;
+      hnx[p] = hny[p] = hnz[p] = 0.0f;
+      if (have_hit[p]) {
+        const float t = best_t[p];
+        hpx[p] = cam.ox + t * dx[p]; hpy[p] = cam.oy + t * dy[p]; hpz[p] = cam.oz + t * dz[p];
+        if (best_prim[p] < ns) {
+          const int g = best_prim[p];
+          float nx = hpx[p] - sc.sph_cx[g], ny = hpy[p] - sc.sph_cy[g], nz = hpz[p] - sc.sph_cz[g];
+          normalize3(nx, ny, nz);
+          hnx[p] = nx; hny[p] = ny; hnz[p] = nz;
+        } else {
+          const float *q = sc.tri + (best_prim[p] - ns);
+          const float pnx = q[0], pny = q[nt], pnz = q[2 * nt];
+          const float rdn = dot3(dx[p], dy[p], dz[p], pnx, pny, pnz);
+          const bool front = rdn < 0;
+          hnx[p] = front ? pnx : -pnx; hny[p] = front ? pny : -pny; hnz[p] = front ? pnz : -pnz;
+        }
+        if (valid[p]) n_hit++;
+      }
+      any_hit |= have_hit[p];
+    }
+    const bool wave_any_hit = __any(any_hit);
+
+    // ---- shadow rays + direct light: core/light.cuh:135-178 ----
+    float lr[P], lg[P], lb[P];
+    bool have_light[P];
+#pragma unroll
+    for (int p = 0; p < P; ++p) { lr[p] = lg[p] = lb[p] = 0.0f; have_light[p] = false; }
+
+    // Streaming scenes restage per light, so every wave of the workgroup must walk the
+    // light loop together; resident scenes let a wave with no hit skip it.
+    if (!A.resident || wave_any_hit) {
+      for (int li = 0; li < sc.nl; ++li) {
+        const int lkind = sc.light_kind[li];
+        const float lvx = sc.light_vec[3 * li], lvy = sc.light_vec[3 * li + 1], lvz = sc.light_vec[3 * li + 2];
+        float sdx[P], sdy[P], sdz[P], sa[P], tl[P], lnx[P], lny[P], lnz[P];
+        bool need[P];
+        bool any_need = false;
+#pragma unroll
+        for (int p = 0; p < P; ++p) {
+          if (lkind == 0) { // DirectionalLight::ray_from, core/light.cuh:73-81
+            sdx[p] = -lvx; sdy[p] = -lvy; sdz[p] = -lvz;
+            tl[p] = MRT_INF;
+            lnx[p] = lvx; lny[p] = lvy; lnz[p] = lvz;
+          } else {          // PointLight::ray_from, core/light.cuh:47-53
+            sdx[p] = lvx - hpx[p]; sdy[p] = lvy - hpy[p]; sdz[p] = lvz - hpz[p];
+            tl[p] = 1.0f;
+            float nx = hpx[p] - lvx, ny = hpy[p] - lvy, nz = hpz[p] - lvz;
+            normalize3(nx, ny, nz);
+            lnx[p] = nx; lny[p] = ny; lnz[p] = nz;
+          }
+          sa[p] = dot3(sdx[p], sdy[p], sdz[p], sdx[p], sdy[p], sdz[p]);
+          // light must not shine through the surface, core/light.cuh:148
+          need[p] = have_hit[p] && !(dot3(sdx[p], sdy[p], sdz[p], hnx[p], hny[p], hnz[p]) < 0);
+          if (need[p] && valid[p]) n_shadow++;
+          any_need |= need[p];
+        }
+        bool open[P]; // still un-occluded
+#pragma unroll
+        for (int p = 0; p < P; ++p) open[p] = need[p];
+
+        // any-hit over spheres, interval [1e-3, t_light] (core/light.cuh:28-33)
+        for (int c0 = 0; c0 < ns; c0 += A.s_cap) {
+          const int cnt = min(A.s_cap, ns - c0);
+          if (!A.resident) {
+            __syncthreads();
+            stage_spheres(sc, cam, L, c0, cnt, 2);
+            __syncthreads();
+          }
+          bool live = false;
+#pragma unroll
+          for (int p = 0; p < P; ++p) live |= open[p];
+          if (!__any(live)) continue; // ballot early-out: nothing left to decide in this wave
+          for (int j = 0; j < cnt; ++j) {
+            const float4 s = L.sphS[j]; // c.xyz, r*r
+            float b[P], disc[P];
+            bool cand = false;
+#pragma unroll
+            for (int p = 0; p < P; ++p) {
+              float ocx = hpx[p] - s.x, ocy = hpy[p] - s.y, ocz = hpz[p] - s.z;
+              b[p] = dot3(ocx, ocy, ocz, sdx[p], sdy[p], sdz[p]);
+              float c = dot3(ocx, ocy, ocz, ocx, ocy, ocz) - s.w;
+              disc[p] = b[p] * b[p] - sa[p] * c;
+              cand |= open[p] && (disc[p] >= 0.0f);
+            }
+            if (cand) {
+              bool still = false;
+#pragma unroll
+              for (int p = 0; p < P; ++p) {
+                if (open[p] && disc[p] >= 0.0f) {
+                  float t;
+                  if (sphere_roots(sa[p], b[p], disc[p], 1e-3f, tl[p], t)) open[p] = false;
+                }
+                still |= open[p];
+              }
+              if (!__any(still)) break;
+            }
+          }
+        }
+        // any-hit over triangles
+        for (int c0 = 0; c0 < nt; c0 += A.t_cap) {
+          const int cnt = min(A.t_cap, nt - c0);
+          if (!A.resident) {
+            __syncthreads();
+            stage_triangles(sc, cam, L, c0, cnt);
+            __syncthreads();
+          }
+          bool live = false;
+#pragma unroll
+          for (int p = 0; p < P; ++p) live |= open[p];
+          if (!__any(live)) continue;
+          for (int j = 0; j < cnt; ++j) {
+            const float4 q0 = L.tri[4 * j + 0], q1 = L.tri[4 * j + 1], q2 = L.tri[4 * j + 2], q3 = L.tri[4 * j + 3];
+            bool blocked = false;
+#pragma unroll
+            for (int p = 0; p < P; ++p) {
+              float rdn = dot3(sdx[p], sdy[p], sdz[p], q0.x, q0.y, q0.z);
+              float t = (q0.w - dot3(hpx[p], hpy[p], hpz[p], q0.x, q0.y, q0.z)) / rdn;
+              float px = hpx[p] + t * sdx[p], py = hpy[p] + t * sdy[p], pz = hpz[p] + t * sdz[p];
+              float e0 = dot3(q1.x, q1.y, q1.z, px, py, pz) - q1.w;
+              float e1 = dot3(q2.x, q2.y, q2.z, px, py, pz) - q2.w;
+              float e2 = dot3(q3.x, q3.y, q3.z, px, py, pz) - q3.w;
+              bool h = (rdn != 0.0f) & (e0 > -1e-6f) & (e1 > -1e-6f) & (e2 > -1e-6f) & (1e-3f <= t) & (t <= tl[p]);
+              if (open[p] && h) { open[p] = false; blocked = true; }
+            }
+            if (__any(blocked)) {
+              bool still = false;
+#pragma unroll
+              for (int p = 0; p < P; ++p) still |= open[p];
+              if (!__any(still)) break;
+            }
+          }
+        }
+
+        // light_bounce with the LIGHT's normal, as the reference passes it (core/light.cuh:164-168)
+        const float lcr = sc.light_rgb[3 * li], lcg = sc.light_rgb[3 * li + 1], lcb = sc.light_rgb[3 * li + 2];
+#pragma unroll
+        for (int p = 0; p < P; ++p) {
+          if (need[p] && !open[p] && valid[p]) n_occl++;
+          if (open[p]) {
+            float cr, cg, cb;
+            const int mk = sc.mat_kind[best_obj[p]];
+            if (mk == 0) { // DiffuseMaterial::light_bounce, core/material.cuh:63-75
+              float scale = -dot3(sdx[p], sdy[p], sdz[p], lnx[p], lny[p], lnz[p]);
+              if (scale > 0.0f) { cr = scale * lcr; cg = scale * lcg; cb = scale * lcb; }
+              else { cr = 0.0f; cg = 0.0f; cb = 0.0f; }
+            } else {       // MetallicMaterial::light_bounce, core/material.cuh:134-158
+              float s2 = 2.0f * dot3(sdx[p], sdy[p], sdz[p], lnx[p], lny[p], lnz[p]);
+              float rx = sdx[p] - s2 * lnx[p], ry = sdy[p] - s2 * lny[p], rz = sdz[p] - s2 * lnz[p];
+              if (dot3(rx, ry, rz, dx[p], dy[p], dz[p]) < -0.99f) { cr = lcr; cg = lcg; cb = lcb; }
+              else { cr = 0.001f; cg = 0.001f; cb = 0.001f; }
+            }
+            if (have_light[p]) { lr[p] += cr; lg[p] += cg; lb[p] += cb; }
+            else { lr[p] = cr; lg[p] = cg; lb[p] = cb; have_light[p] = true; }
+          }
+        }
+      }
+    }
+
+    // ---- combine: src/main.cu:91-104 with MAX_RECURSION_DEPTH = 0 ----
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+      float cr, cg, cb;
+      if (have_hit[p]) {
+        const float *m = sc.mat_rgb + 3 * best_obj[p];
+        const float mr = m[0], mg = m[1], mb = m[2];
+        const float inc = 0.01f; // what the depth-1 call returns, src/main.cu:51-53
+        if (have_light[p]) {
+          cr = inc * mr + lr[p] * mr; cg = inc * mg + lg[p] * mg; cb = inc * mb + lb[p] * mb;
+        } else {
+          cr = inc * mr; cg = inc * mg; cb = inc * mb;
+        }
+      } else {
+        float nx = dx[p], ny = dy[p], nz = dz[p];
+        normalize3(nx, ny, nz);
+        float y = 0.5f * (ny + 1.0f);
+        float w0 = 1.0f - y;
+        cr = w0 * 1.0f + y * 0.5f; cg = w0 * 1.0f + y * 0.7f; cb = w0 * 1.0f + y * 1.0f;
+      }
+      accr[p] += cr; accg[p] += cg; accb[p] += cb; // src/main.cu:151
+      out_id[p] = have_hit[p] ? best_obj[p] : -1;
+      out_t[p] = best_t[p];
+    }
+  }
+
+  // ---- write out: src/main.cu:155 ----
+  const float fn = float(nsamp);
+#pragma unroll
+  for (int p = 0; p < P; ++p) {
+    if (valid[p]) {
+      const size_t pix = size_t(lrow) * A.W + (col0 + p);
+      A.rgb[3 * pix + 0] = accr[p] / fn;
+      A.rgb[3 * pix + 1] = accg[p] / fn;
+      A.rgb[3 * pix + 2] = accb[p] / fn;
+      if (A.id) A.id[pix] = out_id[p];
+      if (A.t) A.t[pix] = out_t[p];
+    }
+  }
+
+  if (A.stats) {
+    // wave reduction, one atomic per wave (only on the stats path, never in timed loops)
+    unsigned int npix = 0;
+#pragma unroll
+    for (int p = 0; p < P; ++p) npix += valid[p] ? 1u : 0u;
+    unsigned int v4[4] = {npix * (unsigned)nsamp, n_shadow, n_hit, n_occl};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      unsigned int x = v4[k];
+      for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, 64);
+      if (lane == 0 && x) atomicAdd(&A.stats[k], (unsigned long long)x);
+    }
+  }
+}
+
+static size_t lds_bytes(int s_cap, int t_cap) { return size_t(2 * s_cap + 4 * t_cap) * 16 + size_t(t_cap) * 4; }
+
+hipError_t launch_render(const RenderArgs &in, hipStream_t stream)
+{
+  RenderArgs A = in;
+  const int ns = A.sc.ns, nt = A.sc.nt;
+  // resident when the whole scene (both sphere records + triangle records) fits in 48 KiB
+  const size_t need = lds_bytes(ns, nt);
+  if (need <= 48 * 1024) {
+    A.resident = 1;
+    A.s_cap = ns > 0 ? ns : 1;
+    A.t_cap = nt > 0 ? nt : 1;
+  } else {
+    A.resident = 0;
+    A.s_cap = 512;  // 2 x 8 KiB sphere records
+    A.t_cap = 256;  // 16 KiB triangle records + 1 KiB numerators
+  }
+  const size_t lds = lds_bytes(A.s_cap, A.t_cap);
+  constexpr int P = 4;
+  dim3 grid((A.W + 32 * P - 1) / (32 * P), (A.local_rows + 7) / 8);
+  if (grid.x == 0 || grid.y == 0) return hipSuccess;
+  hipLaunchKernelGGL(render_kernel<P>, grid, dim3(256), lds, stream, A);
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------
+// batched single-primitive intersection (the reference's hit_sphere / hit_triangle test kernels)
+// ------------------------------------------------------------------------------------------
+
+__global__ __launch_bounds__(256) void intersect_kernel(int prim_kind, const float *__restrict__ prim,
+                                                        const float *__restrict__ rays, float tmin, float tmax,
+                                                        int64_t n, uint8_t *hit, float *t_out, float *point,
+                                                        float *normal)
+{
+  int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float ox = rays[6 * i], oy = rays[6 * i + 1], oz = rays[6 * i + 2];
+  const float dx = rays[6 * i + 3], dy = rays[6 * i + 4], dz = rays[6 * i + 5];
+  bool ok = false;
+  float t = 0.0f, px = 0, py = 0, pz = 0, nx = 0, ny = 0, nz = 0;
+  if (prim_kind == 0) { // Sphere::hit, core/sphere.cuh:32-73
+    const float cx = prim[0], cy = prim[1], cz = prim[2], r = prim[3];
+    float ocx = ox - cx, ocy = oy - cy, ocz = oz - cz;
+    float a = dot3(dx, dy, dz, dx, dy, dz);
+    float b = dot3(ocx, ocy, ocz, dx, dy, dz);
+    float c = dot3(ocx, ocy, ocz, ocx, ocy, ocz) - r * r;
+    float disc = b * b - a * c;
+    ok = sphere_roots(a, b, disc, tmin, tmax, t);
+    if (ok) {
+      px = ox + t * dx; py = oy + t * dy; pz = oz + t * dz;
+      nx = px - cx; ny = py - cy; nz = pz - cz;
+      normalize3(nx, ny, nz);
+    }
+  } else if (prim_kind == 2) { // Triangle::hit, core/triangle.cuh:77-103
+    float rdn = dot3(dx, dy, dz, prim[0], prim[1], prim[2]);
+    if (rdn != 0.0f) {
+      float tt = (prim[3] - dot3(ox, oy, oz, prim[0], prim[1], prim[2])) / rdn;
+      float qx = ox + tt * dx, qy = oy + tt * dy, qz = oz + tt * dz;
+      bool inside = (dot3(prim[4], prim[5], prim[6], qx, qy, qz) - prim[7]) > -1e-6f &&
+                    (dot3(prim[8], prim[9], prim[10], qx, qy, qz) - prim[11]) > -1e-6f &&
+                    (dot3(prim[12], prim[13], prim[14], qx, qy, qz) - prim[15]) > -1e-6f;
+      if (inside && contains(tmin, tmax, tt)) {
+        ok = true; t = tt; px = qx; py = qy; pz = qz;
+        const bool front = rdn < 0;
+        nx = front ? prim[0] : -prim[0]; ny = front ? prim[1] : -prim[1]; nz = front ? prim[2] : -prim[2];
+      }
+    }
+  } // Plane::hit never hits (core/plane.cuh:25-29)
+  hit[i] = ok ? 1 : 0;
+  t_out[i] = t;
+  point[3 * i] = px; point[3 * i + 1] = py; point[3 * i + 2] = pz;
+  normal[3 * i] = nx; normal[3 * i + 1] = ny; normal[3 * i + 2] = nz;
+}
+
+hipError_t launch_intersect(int prim_kind, const float *prim_dev, const float *rays_dev, float tmin, float tmax,
+                            int64_t n, uint8_t *hit_dev, float *t_dev, float *point_dev, float *normal_dev,
+                            hipStream_t stream)
+{
+  if (n <= 0) return hipSuccess;
+  const unsigned blocks = unsigned((n + 255) / 256);
+  hipLaunchKernelGGL(intersect_kernel, dim3(blocks), dim3(256), 0, stream, prim_kind, prim_dev, rays_dev, tmin, tmax,
+                     n, hit_dev, t_dev, point_dev, normal_dev);
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------
+// strip assembly on rank 0 after the gather
+// ------------------------------------------------------------------------------------------
+
+__global__ __launch_bounds__(256) void assemble_kernel(const uint32_t *__restrict__ gathered, size_t rank_stride,
+                                                       uint32_t *__restrict__ frame, int W, int H, int ed, int nranks,
+                                                       int strip_rows)
+{
+  const size_t row_dwords = size_t(W) * ed;
+  const size_t total = size_t(H) * row_dwords;
+  for (size_t i = size_t(blockIdx.x) * blockDim.x + threadIdx.x; i < total; i += size_t(gridDim.x) * blockDim.x) {
+    const int row = int(i / row_dwords);
+    const size_t within = i - size_t(row) * row_dwords;
+    const int strip = row / strip_rows;
+    const int r = strip % nranks;
+    const int lrow = (strip / nranks) * strip_rows + (row - strip * strip_rows);
+    frame[i] = gathered[size_t(r) * rank_stride + size_t(lrow) * row_dwords + within];
+  }
+}
+
+hipError_t launch_assemble(const uint32_t *gathered, size_t rank_stride_elems, uint32_t *frame, int W, int H,
+                           int elem_dwords, int nranks, int strip_rows, hipStream_t stream)
+{
+  const size_t total = size_t(W) * H * elem_dwords;
+  if (total == 0) return hipSuccess;
+  unsigned blocks = unsigned((total + 255) / 256);
+  if (blocks > 256u * 32u) blocks = 256u * 32u;
+  hipLaunchKernelGGL(assemble_kernel, dim3(blocks), dim3(256), 0, stream, gathered, rank_stride_elems, frame, W, H,
+                     elem_dwords, nranks, strip_rows);
+  return hipGetLastError();
+}
+
+} // namespace mrt

@@ -1,0 +1,41 @@
+// app/raytracing_main.cpp -- the reference's CLI, `raytracing <image-filename>`
+// (src/main.cu:159-260), on the MI355X back end: build the hard-coded scene, render on one
+// GPU through the C-ABI, flip, write a Radiance .hdr.  Optional: width height spp.
+#include <cstdio>
+#include <cstdlib>
+
+#include "io/hdr_writer.hpp"
+#include "pipeline/default_scene.hpp"
+#include "pipeline/render.hpp"
+
+static void print_help_and_exit(const char *name)
+{
+  std::printf("usage %s <image-filename> [width height [spp]]\n", name);
+  std::exit(EXIT_FAILURE);
+}
+
+int main(int argc, char **argv)
+{
+  if (argc != 2 && argc != 4 && argc != 5) print_help_and_exit(*argv);
+  std::size_t W = 2048, H = 1024; // src/main.cu:165
+  int spp = 1;
+  if (argc >= 4) { W = std::strtoul(argv[2], nullptr, 10); H = std::strtoul(argv[3], nullptr, 10); }
+  if (argc == 5) spp = std::atoi(argv[4]);
+  if (W == 0 || H == 0) print_help_and_exit(*argv);
+
+  rt::ImageBuffer img(W, H);
+  auto viewport = rt::config::make_viewport(float(W) / float(H));
+  auto scene = rt::config::make_default_scene();
+
+  rt::Renderer renderer(0);
+  renderer.upload(rt::make_view(scene.objects), rt::make_view(scene.lights));
+  mrt_stats st = renderer.render(viewport, img, spp, 0);
+  std::printf("rendered %zux%zu spp %d: %llu primary + %llu shadow rays, kernel %.3f ms\n", W, H, spp,
+              (unsigned long long)st.primary_rays, (unsigned long long)st.shadow_rays, st.kernel_ms);
+
+  img.flip_vertical();
+  std::printf("writing %s...\n", argv[1]);
+  if (!rt::write_hdr(argv[1], img)) { std::fprintf(stderr, "cannot write %s\n", argv[1]); return EXIT_FAILURE; }
+  std::printf("done!\n");
+  return 0;
+}

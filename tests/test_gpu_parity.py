@@ -1,0 +1,352 @@
+"""Parity of the gfx950 path against the CPU oracle, through the C-ABI (libmrt.so).
+
+Bar (BASELINE.json north_star): hit mask, object IDs and t bit-identical; RGB within 1/255
+per channel after clamping to [0,1] (we also assert the max abs float difference, which is
+expected to be exactly 0 because both sides run the same fp32 operation order with FMA
+contraction off)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import _oracle as O
+from raytracing_amd import capi, scenes
+
+pytestmark = pytest.mark.gpu
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+RGB_TOL = 1.0 / 255.0
+
+
+def _load(name):
+    with open(os.path.join(GOLD, name)) as f:
+        return json.load(f)
+
+
+def assert_frame_parity(gpu, ref, what=""):
+    assert np.array_equal(gpu["id"], ref["id"]), f"{what}: ID buffer differs in {(gpu['id'] != ref['id']).sum()} pixels"
+    assert np.array_equal(gpu["t"], ref["t"]), f"{what}: t buffer differs"
+    d = np.abs(np.clip(gpu["rgb"], 0, 1) - np.clip(ref["rgb"], 0, 1)).max()
+    assert d <= RGB_TOL, f"{what}: clamped RGB differs by {d}"
+    assert np.array_equal(gpu["rgb"], ref["rgb"]), f"{what}: float RGB not bit-identical, max abs diff " \
+                                                   f"{np.abs(gpu['rgb'] - ref['rgb']).max()}"
+
+
+def assert_stats_parity(gs, os_):
+    assert gs["primary_rays"] == os_["primary_rays"]
+    assert gs["shadow_rays"] == os_["shadow_rays"]
+    assert gs["hit_pixels"] == os_["hit_pixels"]
+    assert gs["occluded"] == os_["occluded"]
+
+
+# ------------------------------------------------------------------ single-primitive tests (reference test suite)
+
+KA = _load("reference_known_answers.json")
+
+
+@pytest.mark.parametrize("case", KA["sphere"], ids=lambda c: c["name"])
+def test_sphere_known_answers(gpu_ctx, case):
+    lo, hi = KA["interval"]
+    rays = np.float32([case["origin"] + case["dir"]])
+    hit, t, p, n = gpu_ctx.intersect(capi.GEOM_SPHERE, case["center"] + [case["radius"]], rays, lo, hi)
+    ok, ot, op, on = O.sphere_hit(case["center"], case["radius"], case["origin"], case["dir"], lo, hi)
+    assert hit[0] and ok
+    assert abs(float(t[0]) - case["t"]) <= KA["tolerance"]
+    assert t[0] == ot and np.array_equal(p[0], op) and np.array_equal(n[0], on)
+
+
+@pytest.mark.parametrize("case", KA["triangle"], ids=lambda c: c["name"])
+def test_triangle_known_answers(gpu_ctx, case):
+    lo, hi = KA["interval"]
+    rays = np.float32([case["origin"] + case["dir"]])
+    tri16 = capi.triangle_precompute(np.float32([[case["a"], case["b"], case["c"]]]))[:, 0]
+    hit, t, p, n = gpu_ctx.intersect(capi.GEOM_TRIANGLE, tri16, rays, lo, hi)
+    ok, ot, op, on = O.triangle_hit(case["a"], case["b"], case["c"], case["origin"], case["dir"], lo, hi)
+    assert hit[0] and ok
+    assert abs(float(t[0]) - case["t"]) <= KA["tolerance"]
+    assert t[0] == ot and np.array_equal(p[0], op) and np.array_equal(n[0], on)
+
+
+def _random_rays(n, seed):
+    rng = np.random.default_rng(seed)
+    o = rng.uniform(-3, 3, (n, 3)).astype(np.float32)
+    d = rng.uniform(-1, 1, (n, 3)).astype(np.float32)
+    return np.concatenate([o, d], axis=1)
+
+
+def test_random_rays_vs_sphere_bitwise(gpu_ctx):
+    rays = _random_rays(4000, 1)
+    c, r = (0.5, -0.25, -1.0), 1.5  # many origins are inside: exercises the far-root branch
+    for lo, hi in ((-1.0, 100.0), (0.01, np.inf), (1e-3, 1.0)):
+        hit, t, p, n = gpu_ctx.intersect(capi.GEOM_SPHERE, list(c) + [r], rays, lo, hi)
+        nh = 0
+        for i in range(len(rays)):
+            ok, ot, op, on = O.sphere_hit(c, r, rays[i, :3], rays[i, 3:], lo, hi)
+            assert bool(hit[i]) == ok
+            if ok:
+                nh += 1
+                assert t[i] == ot and np.array_equal(p[i], op) and np.array_equal(n[i], on)
+        assert 0 < nh < len(rays)
+
+
+def test_random_rays_vs_triangle_bitwise(gpu_ctx):
+    rays = _random_rays(4000, 2)
+    a, b, c = (-2.0, -1.5, -1.0), (2.5, -1.0, 0.5), (0.0, 2.0, -0.5)
+    tri16 = capi.triangle_precompute(np.float32([[a, b, c]]))[:, 0]
+    for lo, hi in ((-1.0, 100.0), (0.01, np.inf)):
+        hit, t, p, n = gpu_ctx.intersect(capi.GEOM_TRIANGLE, tri16, rays, lo, hi)
+        nh = 0
+        for i in range(len(rays)):
+            ok, ot, op, on = O.triangle_hit(a, b, c, rays[i, :3], rays[i, 3:], lo, hi)
+            assert bool(hit[i]) == ok
+            if ok:
+                nh += 1
+                assert t[i] == ot and np.array_equal(p[i], op) and np.array_equal(n[i], on)
+        assert 0 < nh < len(rays)
+
+
+def test_plane_never_hits_and_empty_batch(gpu_ctx):
+    rays = _random_rays(64, 3)
+    hit, _, _, _ = gpu_ctx.intersect(capi.GEOM_PLANE, [0, 1, 0, 0], rays, -1.0, 100.0)  # core/plane.cuh:25-29
+    assert not hit.any()
+    hit, t, p, n = gpu_ctx.intersect(capi.GEOM_SPHERE, [0, 0, -2, 1], np.zeros((0, 6), np.float32), -1.0, 100.0)
+    assert hit.shape == (0,)
+
+
+def test_parallel_and_degenerate_rays(gpu_ctx):
+    # ray parallel to the triangle plane (rdn == 0), zero direction, tangent sphere ray (disc == 0)
+    tri = [(0, 1, -1), (-1, -1, -1), (1, -1, -1)]
+    tri16 = capi.triangle_precompute(np.float32([tri]))[:, 0]
+    rays = np.float32([[0, 0, 0, 1, 0, 0], [0, 0, 0, 0, 0, 0], [0, 0, -1, 1, 0, 0]])
+    hit, t, p, n = gpu_ctx.intersect(capi.GEOM_TRIANGLE, tri16, rays, -1.0, 100.0)
+    for i in range(3):
+        ok = O.triangle_hit(*tri, rays[i, :3], rays[i, 3:], -1.0, 100.0)[0]
+        assert bool(hit[i]) == ok
+    rays = np.float32([[-1, 0, 0, 0, 0, -1], [0, 0, 0, 0, 0, 0]])
+    hit, t, p, n = gpu_ctx.intersect(capi.GEOM_SPHERE, [0, 0, -5, 1], rays, -1.0, 100.0)
+    assert hit[0] and t[0] == np.float32(5.0) and not hit[1]
+
+
+# ------------------------------------------------------------------ full frames
+
+def test_default_scene_640x480_plumbing(gpu_ctx):
+    """BASELINE config 1 resolution on the default scene, aspect 2.0 (survey anchors)."""
+    flat, _ = scenes.default_scene()
+    gpu_ctx.upload(flat)
+    cam = capi.default_viewport(2.0)
+    g = gpu_ctx.render(cam, 640, 480)
+    r = O.Scene.default().render(O.default_viewport(2.0), 640, 480)
+    assert_frame_parity(g, r, "default 640x480")
+    assert_stats_parity(g["stats"], r["stats"])
+    a = _load("survey_anchors.json")["frames"][0]
+    assert int((g["id"] == -1).sum()) == a["miss"]
+    assert [int((g["id"] == i).sum()) for i in range(10)] == a["id_histogram"]
+    assert g["stats"]["shadow_rays"] == a["shadow_rays"] and g["stats"]["occluded"] == a["occluded"]
+
+
+@pytest.mark.parametrize("aspect", [2.0, 16.0 / 9.0], ids=["aspect2", "aspect16x9"])
+def test_default_scene_1080p(gpu_ctx, aspect):
+    """BASELINE config 2 (the bench workload) at full size."""
+    flat, _ = scenes.default_scene()
+    gpu_ctx.upload(flat)
+    g = gpu_ctx.render(capi.default_viewport(aspect), 1920, 1080)
+    r = O.Scene.default().render(O.default_viewport(aspect), 1920, 1080, nthreads=8)
+    assert_frame_parity(g, r, f"default 1080p aspect {aspect}")
+    assert_stats_parity(g["stats"], r["stats"])
+    if aspect == 2.0:
+        a = _load("survey_anchors.json")["frames"][1]
+        assert [int((g["id"] == i).sum()) for i in range(10)] == a["id_histogram"]
+        assert g["stats"]["primary_rays"] + g["stats"]["shadow_rays"] == a["total_rays"]
+        mean = g["rgb"].reshape(-1, 3).mean(axis=0, dtype=np.float64)
+        assert np.all(np.abs(mean - np.array(a["mean_rgb"])) < 1e-6)
+
+
+def test_small_sphere_scene_640x480(gpu_ctx):
+    """BASELINE config 1 'small sphere scene': the default scene's four spheres, aspect 4/3."""
+    spec = scenes.small_sphere_scene()
+    gpu_ctx.upload(spec.flatten())
+    cam = spec.cam12(4.0 / 3.0)
+    g = gpu_ctx.render(cam, 640, 480)
+    r = O.Scene.from_spec(spec).render(cam, 640, 480, nthreads=4)
+    assert_frame_parity(g, r, "small spheres")
+    assert (g["id"] >= 0).sum() > 1000
+
+
+@pytest.mark.parametrize("W,H", [(8, 8), (33, 17), (250, 130), (1, 1), (129, 8)])
+def test_ragged_frame_sizes(gpu_ctx, W, H):
+    """The reference asserts W,H multiples of 8 (src/main.cu:174); this path masks partial tiles."""
+    flat, _ = scenes.default_scene()
+    gpu_ctx.upload(flat)
+    cam = capi.default_viewport(W / H)
+    g = gpu_ctx.render(cam, W, H)
+    r = O.Scene.default().render(cam, W, H)
+    assert_frame_parity(g, r, f"{W}x{H}")
+    assert_stats_parity(g["stats"], r["stats"])
+
+
+def test_empty_scene_is_all_sky(gpu_ctx):
+    e = np.zeros(0)
+    flat = capi.FlatScene(e, np.zeros((0, 3)), np.zeros((0, 4)), e, np.zeros((16, 0)), e, e, np.zeros((0, 3)),
+                          np.zeros((0, 3)))
+    gpu_ctx.upload(flat)
+    cam = capi.default_viewport(2.0)
+    g = gpu_ctx.render(cam, 64, 32)
+    r = O.Scene().render(cam, 64, 32)
+    assert (g["id"] == -1).all() and np.isinf(g["t"]).all()
+    assert_frame_parity(g, r, "empty")
+
+
+def test_sphere_field_streaming_path(gpu_ctx):
+    """Config 3 shape (10k spheres: LDS-streamed chunks) at an oracle-sized frame."""
+    spec = scenes.sphere_field(10000)
+    gpu_ctx.upload(spec.flatten())
+    cam = spec.cam12(16.0 / 9.0)
+    g = gpu_ctx.render(cam, 256, 144)
+    r = O.Scene.from_spec(spec).render(cam, 256, 144, nthreads=8)
+    assert_frame_parity(g, r, "10k spheres")
+    assert_stats_parity(g["stats"], r["stats"])
+    assert g["stats"]["shadow_rays"] > 1000 and g["stats"]["occluded"] > 100
+
+
+def test_triangle_terrain_streaming_path(gpu_ctx):
+    """Config 4 shape (triangle mesh streamed through LDS) at an oracle-sized mesh and frame."""
+    spec = scenes.triangle_terrain(100, 50)  # 10 000 triangles
+    gpu_ctx.upload(spec.flatten())
+    cam = spec.cam12(16.0 / 9.0)
+    g = gpu_ctx.render(cam, 256, 144)
+    r = O.Scene.from_spec(spec).render(cam, 256, 144, nthreads=8)
+    assert_frame_parity(g, r, "terrain 10k")
+    assert_stats_parity(g["stats"], r["stats"])
+    assert (g["id"] >= 0).sum() > 5000
+
+
+def test_light_stress_point_lights(gpu_ctx):
+    """Config 5 shape: 64 point lights, spheres and triangles interleaved in object order.
+    PointLight is never instantiated by the reference's render path: parity here is
+    oracle-vs-GPU only ('parity unpinned' against the real reference)."""
+    spec = scenes.light_stress()
+    gpu_ctx.upload(spec.flatten())
+    cam = spec.cam12(16.0 / 9.0)
+    g = gpu_ctx.render(cam, 320, 180)
+    r = O.Scene.from_spec(spec).render(cam, 320, 180, nthreads=8)
+    assert_frame_parity(g, r, "64 lights")
+    assert_stats_parity(g["stats"], r["stats"])
+    assert g["stats"]["shadow_rays"] > 100000
+
+
+def test_mixed_scene_just_over_the_resident_limit(gpu_ctx):
+    """Spheres and triangles both streamed in several chunks, with lights of both kinds."""
+    spec = scenes.light_stress(700, 700, grid=2)
+    spec.lights.insert(1, (capi.LIGHT_DIRECTIONAL, (0.3, -1.0, -0.2), (2.0, 1.0, 0.5)))
+    gpu_ctx.upload(spec.flatten())
+    cam = spec.cam12(16.0 / 9.0)
+    g = gpu_ctx.render(cam, 200, 112)
+    r = O.Scene.from_spec(spec).render(cam, 200, 112, nthreads=8)
+    assert_frame_parity(g, r, "mixed streaming")
+    assert_stats_parity(g["stats"], r["stats"])
+
+
+def test_closest_hit_ties_across_primitive_types(gpu_ctx):
+    """Coincident primitives: the lowest object number wins (src/main.cu:70 strict '<'), also when
+    the tie is between a sphere and a triangle that live in different SoA arrays."""
+    tri = [(-3, -3, -4), (3, -3, -4), (0, 3, -4)]
+    for order in ("tri_first", "sphere_first"):
+        # the sphere's near surface touches z = -4 at the centre pixel, where the triangle also lies
+        if order == "tri_first":
+            spec = scenes.SceneSpec("tie", [[0, 0, -5, 1]], [1], [tri, tri], [0, 2], [0, 0, 0],
+                                    [[.5, .5, .5]] * 3, [(0, (0, -1, -1), (1, 1, 1))], scenes._camera(40.0))
+        else:
+            spec = scenes.SceneSpec("tie", [[0, 0, -5, 1], [0, 0, -5, 1]], [0, 1], [tri], [2], [0, 0, 0],
+                                    [[.5, .5, .5]] * 3, [(0, (0, -1, -1), (1, 1, 1))], scenes._camera(40.0))
+        spec.camera.update(look_from=(0, 0, 0), look_at=(0, 0, -1))
+        gpu_ctx.upload(spec.flatten())
+        cam = spec.cam12(1.0)
+        g = gpu_ctx.render(cam, 65, 65)
+        r = O.Scene.from_spec(spec).render(cam, 65, 65)
+        assert_frame_parity(g, r, order)
+        assert (g["id"] == 0).sum() > 0
+        if order == "sphere_first":
+            assert (g["id"] == 1).sum() == 0
+
+
+def test_multisample_121_mode(gpu_ctx):
+    """rt::MultisampleMesh mode (pipeline/multisample_mesh.cuh): 121 samples per pixel."""
+    flat, _ = scenes.default_scene()
+    gpu_ctx.upload(flat)
+    cam = capi.default_viewport(2.0)
+    g = gpu_ctx.render(cam, 128, 64, spp=121)
+    r = O.Scene.default().render(cam, 128, 64, spp=121, nthreads=8)
+    assert_frame_parity(g, r, "121 spp")
+    assert g["stats"]["primary_rays"] == 128 * 64 * 121
+    assert_stats_parity(g["stats"], r["stats"])
+
+
+# ------------------------------------------------------------------ strips (multi-GPU partition on one GPU)
+
+@pytest.mark.parametrize("nranks,strip", [(2, 8), (3, 8), (8, 8), (4, 16)])
+def test_strip_partition_reassembles_bitwise(gpu_ctx, nranks, strip):
+    flat, _ = scenes.default_scene()
+    gpu_ctx.upload(flat)
+    W, H = 480, 270  # 270 rows: uneven strip counts per rank
+    cam = capi.default_viewport(W / H)
+    full = gpu_ctx.render(cam, W, H)
+    out = {k: np.zeros_like(full[k]) for k in ("rgb", "id", "t")}
+    tot = {"primary_rays": 0, "shadow_rays": 0, "hit_pixels": 0, "occluded": 0}
+    for rank in range(nranks):
+        part = gpu_ctx.render(cam, W, H, rank=rank, num_ranks=nranks, strip_rows=strip)
+        rows = capi.local_row_index(H, rank, nranks, strip)
+        assert part["rgb"].shape[0] == len(rows)
+        for k in out:
+            out[k][rows] = part[k]
+        for k in tot:
+            tot[k] += part["stats"][k]
+    for k in out:
+        assert np.array_equal(out[k], full[k]), k
+    for k in tot:
+        assert tot[k] == full["stats"][k]
+
+
+def test_device_render_and_strip_assembly(gpu_ctx):
+    """mrt_render_device + mrt_assemble_strips with torch-owned HBM buffers (the bench path)."""
+    torch = pytest.importorskip("torch")
+    flat, _ = scenes.default_scene()
+    gpu_ctx.upload(flat)
+    W, H, nranks = 320, 200, 4
+    cam = capi.default_viewport(W / H)
+    full = gpu_ctx.render(cam, W, H)
+    dev = torch.device("cuda:0")
+    max_rows = capi.local_rows(H, 0, nranks)
+    gathered = torch.zeros((nranks, max_rows * W * 3), dtype=torch.float32, device=dev)
+    gathered_id = torch.full((nranks, max_rows * W), -7, dtype=torch.int32, device=dev)
+    stream = torch.cuda.current_stream().cuda_stream
+    for rank in range(nranks):
+        gpu_ctx.render_device(cam, W, H, gathered[rank].data_ptr(), id_ptr=gathered_id[rank].data_ptr(), stream=stream,
+                              rank=rank, num_ranks=nranks)
+    frame = torch.zeros((H, W, 3), dtype=torch.float32, device=dev)
+    frame_id = torch.zeros((H, W), dtype=torch.int32, device=dev)
+    gpu_ctx.assemble_strips(gathered.data_ptr(), gathered.shape[1], frame.data_ptr(), W, H, 3, nranks, stream=stream)
+    gpu_ctx.assemble_strips(gathered_id.data_ptr(), gathered_id.shape[1], frame_id.data_ptr(), W, H, 1, nranks,
+                            stream=stream)
+    torch.cuda.synchronize()
+    assert np.array_equal(frame.cpu().numpy(), full["rgb"])
+    assert np.array_equal(frame_id.cpu().numpy(), full["id"])
+
+
+def test_error_paths(gpu_ctx):
+    ctx = capi.Context(0)
+    with pytest.raises(capi.MrtError, match="no scene"):
+        ctx.render(capi.default_viewport(2.0), 16, 16)
+    flat, _ = scenes.default_scene()
+    ctx.upload(flat)
+    with pytest.raises(capi.MrtError):
+        ctx.render(capi.default_viewport(2.0), 16, 16, spp=7)
+    with pytest.raises(capi.MrtError):
+        ctx.render(capi.default_viewport(2.0), 16, 16, max_depth=3)
+    with pytest.raises(capi.MrtError):
+        ctx.render(capi.default_viewport(2.0), 0, 16)
+    bad = scenes.default_scene()[0]
+    bad.sphere_obj = bad.sphere_obj[::-1].copy()  # not ascending
+    with pytest.raises(capi.MrtError):
+        ctx.upload(bad)
+    ctx.close()
