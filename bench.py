@@ -1,0 +1,209 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark: Mrays/s (primary + shadow) of the render hot path.
+
+    python bench.py --gpus N --steps K --warmup W [--config C2|C3|C4|C5]
+
+A "step" is one frame of the configured workload: every rank renders its strips of the frame
+with the HIP back end (scene already resident in HBM), and for N > 1 the strips are gathered
+to rank 0 over RCCL and assembled.  Default workload = BASELINE.json configs[1]: the
+reference's default scene (src/main.cu:183-237) at 1920x1080, 1 spp, primary + shadow rays.
+
+Prints ONE JSON line on rank 0 (contract in the task statement), including
+  roofline      -- dominant kernel (render_kernel) vs the HBM roof, algorithmic bytes/launch
+  roofline_valu -- the same launches vs the fp32 vector-ALU roof, algorithmic flops/launch
+  cpu_baseline  -- the CPU oracle ("port") timed on this host, bounded sample (rank 0, N=1 only)
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+VALU_PEAK_TFLOPS = 157.3     # fp32 vector peak (packed FMA); no-FMA packed ceiling is half, plain a quarter
+BYTES_PER_PIXEL = 20         # RGB f32 + id i32 + t f32
+
+
+def build_workload(name):
+    """-> (flat scene, cam12, W, H, flops_per_ray, scene_bytes, oracle scene factory, label)"""
+    from raytracing_amd import capi, scenes
+
+    if name == "C2":
+        flat, cam = scenes.default_scene()
+        W, H = 1920, 1080
+        cam12 = capi.viewport(cam["look_from"], cam["look_at"], cam["up"], cam["vfov"], W / H)
+        label = "default main.cu scene (4 spheres + 6 triangles, 1 directional light), 1920x1080, 1 spp, depth 0"
+        spec = None
+    else:
+        if name == "C3":
+            spec, (W, H) = scenes.sphere_field(10000), (3840, 2160)
+            label = "10k random spheres, 3840x2160, 1 spp, depth 0"
+        elif name == "C4":
+            spec, (W, H) = scenes.triangle_terrain(1000, 500), (3840, 2160)
+            label = "1M-triangle terrain, 3840x2160, 1 spp, depth 0"
+        elif name == "C5":
+            spec, (W, H) = scenes.light_stress(), (1920, 1080)
+            label = "256 spheres + 256 triangles, 64 point lights, 1920x1080, 1 spp, depth 0"
+        else:
+            raise SystemExit(f"unknown config {name}")
+        flat = spec.flatten()
+        cam12 = spec.cam12(W / H)
+    flops = 23 * flat.num_spheres + 36 * flat.num_triangles
+    scene_bytes = 16 * flat.num_spheres + 64 * flat.num_triangles
+    return flat, cam12, W, H, flops, scene_bytes, spec, label
+
+
+def cpu_baseline(name, spec, cam12, W, H, total_rays_full):
+    """Time the CPU oracle (a scalar port of the reference path) on this host: bounded sample."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import _oracle as O  # test infrastructure, used here only as the reported CPU baseline
+
+    scene = O.Scene.default() if spec is None else O.Scene.from_spec(spec)
+    threads = min(16, os.cpu_count() or 1)  # the GPU box's CPU share for one GPU is 16
+    if name == "C2":
+        rows, sw, sh = (0, H), W, H
+    else:  # brute force on the CPU is slow: render a reduced frame and scale per ray
+        sw, sh = W // 8, H // 8
+        rows = (0, sh)
+    out = {}
+    for label, nt in (("1thread", 1), ("threads", threads)):
+        budget, frames, t0, rays = (4.0 if nt == 1 else 8.0), 0, time.perf_counter(), 0
+        while True:
+            r = scene.render(cam12, sw, sh, rows=rows, nthreads=nt, want=("rgb", "id", "t"))
+            rays += r["stats"]["primary_rays"] + r["stats"]["shadow_rays"]
+            frames += 1
+            dt = time.perf_counter() - t0
+            if dt >= budget or frames >= 200:
+                break
+        out[label] = (rays / dt / 1e6, frames, dt)
+    v1, vn = out["1thread"], out["threads"]
+    return {
+        "value": round(vn[0], 3), "unit": "Mrays/s", "cores": threads, "kind": "port",
+        "sample": f"{vn[1]} frame(s) of the same scene at {sw}x{sh} in {vn[2]:.1f}s on {threads} threads "
+                  f"(rows split statically); single thread: {v1[0]:.3f} Mrays/s over {v1[1]} frame(s)",
+        "value_1thread": round(v1[0], 3),
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=None)
+    ap.add_argument("--warmup", type=int, default=None)
+    ap.add_argument("--config", default="C2")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-ids", action="store_true", help="write RGB only (12 B/pixel)")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    from raytracing_amd import multigpu
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+        args.gpus = world
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: there is no CPU fallback of the product path")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+
+    flat, cam12, W, H, flops_ray, scene_bytes, spec, label = build_workload(args.config)
+    heavy = args.config in ("C3", "C4")
+    steps = args.steps if args.steps is not None else (3 if args.config == "C4" else (20 if heavy else 500))
+    warmup = args.warmup if args.warmup is not None else (1 if heavy else 50)
+
+    fr = multigpu.FrameRenderer(flat, cam12, W, H, rank=rank, num_ranks=world, device=local_rank,
+                                with_ids=not args.no_ids)
+    bytes_pp = 12 if args.no_ids else BYTES_PER_PIXEL
+
+    # rays per frame (deterministic for a scene + camera): counted once, outside the timed region
+    mine = fr.count_rays()
+    cnt = torch.tensor([mine["primary_rays"], mine["shadow_rays"], fr.local_rows * W], dtype=torch.int64,
+                       device=fr.dev)
+    if world > 1:
+        dist.all_reduce(cnt)
+    primary, shadow, _ = (int(x) for x in cnt.cpu())
+    rays_per_frame = primary + shadow
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(warmup):
+        fr.step()
+    sync()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+    t0 = time.perf_counter()
+    for k in range(steps):
+        # HIP events on the stream the kernel is launched on (torch's current stream), around the
+        # render kernel only: the gather/assembly of step() follow the second event
+        ev[k][0].record()
+        fr.render_local()
+        ev[k][1].record()
+        if world > 1:
+            multigpu.gather_strips(fr.rgb, world, rank, dst=0, out=fr.gathered)
+            if rank == 0:
+                fr.ctx.assemble_strips(fr.gathered.data_ptr(), fr.gathered.shape[1], fr.frame.data_ptr(), W, H, 3,
+                                       world, fr.strip_rows, stream=torch.cuda.current_stream().cuda_stream)
+    sync()
+    elapsed = time.perf_counter() - t0
+    el = torch.tensor([elapsed], dtype=torch.float64, device=fr.dev)
+    if world > 1:
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+    elapsed = float(el.item())
+    kern_ms = sum(a.elapsed_time(b) for a, b in ev) / steps
+
+    if rank == 0:
+        ms_per_step = elapsed / steps * 1e3
+        value = rays_per_frame * steps / elapsed / 1e6
+        # dominant kernel = render_kernel; per launch this rank processes its own strips
+        my_pixels = fr.local_rows * W
+        my_rays = mine["primary_rays"] + mine["shadow_rays"]
+        alg_bytes = my_pixels * bytes_pp + scene_bytes
+        alg_flops = my_rays * flops_ray
+        ach_gbs = alg_bytes / (kern_ms * 1e-3) / 1e9
+        ach_tf = alg_flops / (kern_ms * 1e-3) / 1e12
+        out = {
+            "metric": "Mrays/s (primary+shadow) at 1920x1080" if args.config in ("C2", "C5") else
+                      "Mrays/s (primary+shadow) at 3840x2160",
+            "value": round(value, 3), "unit": "Mrays/s", "n_gpus": world, "steps": steps, "warmup": warmup,
+            "ms_per_step": round(ms_per_step, 5), "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{args.config}: {label}", "width": W, "height": H, "spp": 1, "max_depth": 0,
+                       "primary_rays": primary, "shadow_rays": shadow,
+                       "parallelism": f"{world} GPU(s): 8-row strips round-robin, scene replicated" +
+                                      ("" if world == 1 else ", RCCL gather to rank 0 + strip assembly"),
+                       "outputs": "rgb f32 + id i32 + t f32" if not args.no_ids else "rgb f32"},
+            "roofline": {"bound": "hbm", "achieved": round(ach_gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(ach_gbs / HBM_PEAK_GBS, 5), "traffic": None,
+                         "kernel": "render_kernel", "kernel_ms": round(kern_ms, 5),
+                         "algorithmic_bytes_per_launch": alg_bytes},
+            "roofline_valu": {"bound": "fp32 vector ALU (no MFMA: no dense contraction)",
+                              "achieved": round(ach_tf, 4), "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
+                              "frac": round(ach_tf / VALU_PEAK_TFLOPS, 5),
+                              "frac_of_no_fma_packed_ceiling": round(ach_tf / (VALU_PEAK_TFLOPS / 2), 5),
+                              "algorithmic_flops_per_ray": flops_ray, "algorithmic_flops_per_launch": alg_flops},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.config, spec, cam12, W, H, rays_per_frame)
+        print(json.dumps(out), flush=True)
+
+    fr.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

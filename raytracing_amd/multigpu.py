@@ -62,18 +62,26 @@ class FrameRenderer:
         self.stats = torch.zeros(4, dtype=torch.int64, device=self.dev)
         self.gathered = None
         self.frame = None
+        self._call = None
         if rank == 0 and num_ranks > 1:
             self.gathered = torch.empty((num_ranks, n * 3), dtype=torch.float32, device=self.dev)
             self.frame = torch.empty((height, width, 3), dtype=torch.float32, device=self.dev)
 
     def render_local(self, want_stats=False):
         """Enqueue this rank's strips on torch's current stream (asynchronous)."""
-        stream = self.torch.cuda.current_stream(self.dev).cuda_stream
-        self.ctx.render_device(self.cam12, self.W, self.H, self.rgb.data_ptr(),
-                               id_ptr=self.ids.data_ptr() if self.ids is not None else None,
-                               t_ptr=self.tt.data_ptr() if self.tt is not None else None,
-                               stats_ptr=self.stats.data_ptr() if want_stats else None, stream=stream, spp=self.spp,
-                               rank=self.rank, num_ranks=self.num_ranks, strip_rows=self.strip_rows)
+        import ctypes as C
+        if self._call is None:  # argument structs are built once: a frame is tens of microseconds
+            cam = capi.Camera.from12(self.cam12)
+            par = capi.Context._params(self.W, self.H, self.spp, 0, self.rank, self.num_ranks, self.strip_rows)
+            self._call = (cam, par, C.byref(cam), C.byref(par), C.c_void_p(self.rgb.data_ptr()),
+                          C.c_void_p(self.ids.data_ptr()) if self.ids is not None else None,
+                          C.c_void_p(self.tt.data_ptr()) if self.tt is not None else None,
+                          C.c_void_p(self.stats.data_ptr()))
+        _, _, cam_p, par_p, rgb_p, id_p, t_p, st_p = self._call
+        stream = C.c_void_p(self.torch.cuda.current_stream(self.dev).cuda_stream)
+        rc = self.ctx._L.mrt_render_device(self.ctx._h, cam_p, par_p, rgb_p, id_p, t_p, st_p if want_stats else None,
+                                           stream)
+        self.ctx._check(rc, "mrt_render_device")
 
     def step(self):
         """One frame: render local strips, gather to rank 0, assemble.  Asynchronous."""

@@ -248,26 +248,35 @@ def test_mixed_scene_just_over_the_resident_limit(gpu_ctx):
 
 
 def test_closest_hit_ties_across_primitive_types(gpu_ctx):
-    """Coincident primitives: the lowest object number wins (src/main.cu:70 strict '<'), also when
-    the tie is between a sphere and a triangle that live in different SoA arrays."""
+    """Exact t ties: the lowest object number wins (src/main.cu:70 strict '<'), also when the tie is
+    between a sphere and a triangle that live in different SoA arrays.  The centre ray of a 64x64
+    frame is exactly (0,0,-1): it meets the plane z=-4 and the sphere's near pole at t == 4.0."""
     tri = [(-3, -3, -4), (3, -3, -4), (0, 3, -4)]
-    for order in ("tri_first", "sphere_first"):
-        # the sphere's near surface touches z = -4 at the centre pixel, where the triangle also lies
-        if order == "tri_first":
-            spec = scenes.SceneSpec("tie", [[0, 0, -5, 1]], [1], [tri, tri], [0, 2], [0, 0, 0],
-                                    [[.5, .5, .5]] * 3, [(0, (0, -1, -1), (1, 1, 1))], scenes._camera(40.0))
-        else:
-            spec = scenes.SceneSpec("tie", [[0, 0, -5, 1], [0, 0, -5, 1]], [0, 1], [tri], [2], [0, 0, 0],
-                                    [[.5, .5, .5]] * 3, [(0, (0, -1, -1), (1, 1, 1))], scenes._camera(40.0))
+    light = [(0, (0, -1, -1), (1, 1, 1))]
+    rgb = [[.5, .5, .5]] * 3
+    cases = {
+        # triangle is object 0, sphere object 1: the GPU walks spheres first, so the tie rule must hand
+        # the pixel back to the triangle
+        "tri_then_sphere": scenes.SceneSpec("tie", [[0, 0, -5, 1]], [1], [tri], [0], [0, 0], rgb[:2], light,
+                                            scenes._camera(40.0)),
+        "sphere_then_tri": scenes.SceneSpec("tie", [[0, 0, -5, 1]], [0], [tri], [1], [0, 0], rgb[:2], light,
+                                            scenes._camera(40.0)),
+        "coincident_spheres_and_tris": scenes.SceneSpec("tie", [[0, 0, -3.5, 1], [0, 0, -3.5, 1]], [1, 2],
+                                                        [tri, tri], [0, 3], [0, 0, 0, 0], rgb + rgb[:1], light,
+                                                        scenes._camera(40.0)),
+    }
+    for name, spec in cases.items():
         spec.camera.update(look_from=(0, 0, 0), look_at=(0, 0, -1))
         gpu_ctx.upload(spec.flatten())
         cam = spec.cam12(1.0)
-        g = gpu_ctx.render(cam, 65, 65)
-        r = O.Scene.from_spec(spec).render(cam, 65, 65)
-        assert_frame_parity(g, r, order)
-        assert (g["id"] == 0).sum() > 0
-        if order == "sphere_first":
-            assert (g["id"] == 1).sum() == 0
+        g = gpu_ctx.render(cam, 64, 64)
+        r = O.Scene.from_spec(spec).render(cam, 64, 64)
+        assert_frame_parity(g, r, name)
+        if name != "coincident_spheres_and_tris":
+            assert g["t"][32, 32] == np.float32(4.0) and g["id"][32, 32] == 0
+        else:
+            assert set(np.unique(g["id"])) == {-1, 0, 1}  # objects 2 and 3 never win their ties
+    assert (gpu_ctx.render(cam, 64, 64)["id"] == 1).sum() > 100
 
 
 def test_multisample_121_mode(gpu_ctx):
