@@ -140,7 +140,7 @@ int mrt_render(mrt_ctx *ctx, const mrt_camera *cam, const mrt_render_params *par
 
 /*
  * Asynchronous render into DEVICE buffers on a caller-supplied HIP stream
- * (hipStream_t passed as void*, NULL = the context's own stream).  Same layout
+ * (hipStream_t passed as void*; NULL = HIP's default stream, as in HIP itself).  Same layout
  * as mrt_render.  stats_dev, if not NULL, points to 4 device uint64 that receive
  * primary/shadow/hit/occluded counts.  The caller synchronises.
  */

@@ -247,7 +247,7 @@ int mrt_render_device(mrt_ctx *ctx, const mrt_camera *cam, const mrt_render_para
   A.rgb = (float *)rgb_dev; A.id = (int32_t *)id_dev; A.t = (float *)t_dev;
   A.stats = (unsigned long long *)stats_dev;
   HIP_TRY(ctx, hipSetDevice(ctx->device));
-  hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
+  hipStream_t st = (hipStream_t)stream; // NULL = HIP's default stream, as everywhere in HIP
   if (A.stats) HIP_TRY(ctx, hipMemsetAsync(A.stats, 0, 4 * sizeof(unsigned long long), st));
   HIP_TRY(ctx, mrt::launch_render(A, st));
   return MRT_OK;
@@ -306,7 +306,7 @@ int mrt_assemble_strips(mrt_ctx *ctx, const void *gathered_dev, size_t rank_stri
   if ((size_t)local_rows_of(height, p0) * width * elem_dwords > rank_stride_elems)
     return fail(ctx, MRT_ERR_INVALID, "rank stride smaller than a rank's strip buffer");
   HIP_TRY(ctx, hipSetDevice(ctx->device));
-  hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
+  hipStream_t st = (hipStream_t)stream;
   HIP_TRY(ctx, mrt::launch_assemble((const uint32_t *)gathered_dev, rank_stride_elems, (uint32_t *)frame_dev, width,
                                     height, elem_dwords, num_ranks, strip_rows, st));
   return MRT_OK;
