@@ -19,6 +19,8 @@
 
 #include "mrt_internal.h"
 
+#include <cstdlib>
+
 namespace mrt {
 
 #define MRT_INF __builtin_inff()
@@ -63,7 +65,14 @@ __device__ __forceinline__ bool sphere_roots(float a, float b, float disc, float
 //          [s_cap, 2 s_cap)      sphere shadow records
 //          [2 s_cap, +4 t_cap)   triangle records (4 float4 each)
 //          then t_cap floats     primary numerators kp - o.pn
+// Chunks are padded to a multiple of the unroll factor with records that can never hit:
+//   sphere primary (0,0,0,+inf): disc = b*b - a*inf is -inf or NaN, never >= 0
+//   sphere shadow  (0,0,0,-inf): c = oc.oc + inf = +inf, same
+//   triangle       pn = 0:       rdn == 0, rejected by the rdn != 0 test
 // ------------------------------------------------------------------------------------------
+
+constexpr int US = 8; // spheres per unrolled block (8 x 16 B prefetched per block)
+constexpr int UT = 2; // triangles per unrolled block (2 x 68 B)
 
 struct LdsPlan {
   float4 *sphP, *sphS, *tri;
@@ -80,20 +89,28 @@ __device__ __forceinline__ LdsPlan lds_plan(float4 *base, int s_cap, int t_cap)
   return p;
 }
 
+__device__ __forceinline__ int round_up(int x, int m) { return (x + m - 1) / m * m; }
+
 // which: bit0 primary records, bit1 shadow records
 __device__ __forceinline__ void stage_spheres(const DevScene &sc, const DevCamera &cam, const LdsPlan &L, int begin,
                                               int count, int which)
 {
-  for (int i = threadIdx.x; i < count; i += blockDim.x) {
-    int g = begin + i;
-    float cx = sc.sph_cx[g], cy = sc.sph_cy[g], cz = sc.sph_cz[g], r = sc.sph_r[g];
-    float rr = r * r;
-    if (which & 1) {
-      float ocx = cam.ox - cx, ocy = cam.oy - cy, ocz = cam.oz - cz;
-      float c = dot3(ocx, ocy, ocz, ocx, ocy, ocz) - rr;
-      L.sphP[i] = make_float4(ocx, ocy, ocz, c);
+  const int padded = round_up(count, US);
+  for (int i = threadIdx.x; i < padded; i += blockDim.x) {
+    if (i < count) {
+      int g = begin + i;
+      float cx = sc.sph_cx[g], cy = sc.sph_cy[g], cz = sc.sph_cz[g], r = sc.sph_r[g];
+      float rr = r * r;
+      if (which & 1) {
+        float ocx = cam.ox - cx, ocy = cam.oy - cy, ocz = cam.oz - cz;
+        float c = dot3(ocx, ocy, ocz, ocx, ocy, ocz) - rr;
+        L.sphP[i] = make_float4(ocx, ocy, ocz, c);
+      }
+      if (which & 2) L.sphS[i] = make_float4(cx, cy, cz, rr);
+    } else {
+      if (which & 1) L.sphP[i] = make_float4(0.0f, 0.0f, 0.0f, MRT_INF);
+      if (which & 2) L.sphS[i] = make_float4(0.0f, 0.0f, 0.0f, -MRT_INF);
     }
-    if (which & 2) L.sphS[i] = make_float4(cx, cy, cz, rr);
   }
 }
 
@@ -101,17 +118,275 @@ __device__ __forceinline__ void stage_triangles(const DevScene &sc, const DevCam
                                                 int count)
 {
   const int nt = sc.nt;
-  for (int i = threadIdx.x; i < count; i += blockDim.x) {
-    const float *p = sc.tri + begin + i;
-    float4 q0 = make_float4(p[0], p[nt], p[2 * nt], p[3 * nt]);
-    float4 q1 = make_float4(p[4 * nt], p[5 * nt], p[6 * nt], p[7 * nt]);
-    float4 q2 = make_float4(p[8 * nt], p[9 * nt], p[10 * nt], p[11 * nt]);
-    float4 q3 = make_float4(p[12 * nt], p[13 * nt], p[14 * nt], p[15 * nt]);
+  const int padded = round_up(count, UT);
+  for (int i = threadIdx.x; i < padded; i += blockDim.x) {
+    float4 q0, q1, q2, q3;
+    if (i < count) {
+      const float *p = sc.tri + begin + i;
+      q0 = make_float4(p[0], p[nt], p[2 * nt], p[3 * nt]);
+      q1 = make_float4(p[4 * nt], p[5 * nt], p[6 * nt], p[7 * nt]);
+      q2 = make_float4(p[8 * nt], p[9 * nt], p[10 * nt], p[11 * nt]);
+      q3 = make_float4(p[12 * nt], p[13 * nt], p[14 * nt], p[15 * nt]);
+    } else {
+      q0 = q1 = q2 = q3 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    }
     L.tri[4 * i + 0] = q0;
     L.tri[4 * i + 1] = q1;
     L.tri[4 * i + 2] = q2;
     L.tri[4 * i + 3] = q3;
     L.triNum[i] = q0.w - dot3(cam.ox, cam.oy, cam.oz, q0.x, q0.y, q0.z);
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// Inner loops.  Every loop walks one staged chunk in blocks of U primitives: the records of
+// a block are read from LDS back to back (broadcast reads: all lanes use the same address), then the
+// whole block is evaluated, so one LDS round trip is paid per U primitives and the other waves of the
+// SIMD cover it.
+// ------------------------------------------------------------------------------------------
+
+struct Tri {
+  float4 q0, q1, q2, q3;
+  float num;
+};
+
+__device__ __forceinline__ Tri load_tri(const LdsPlan &L, int j)
+{
+  Tri t;
+  t.q0 = L.tri[4 * j + 0]; t.q1 = L.tri[4 * j + 1]; t.q2 = L.tri[4 * j + 2]; t.q3 = L.tri[4 * j + 3];
+  t.num = L.triNum[j];
+  return t;
+}
+
+// closest hit over one chunk of sphere primary records (src/main.cu:60-77, core/sphere.cuh:32-73)
+template <int P>
+__device__ __forceinline__ void closest_spheres(const float4 *__restrict__ rec, int padded, int prim0,
+                                                const int32_t *__restrict__ sph_obj, const float (&dx)[P],
+                                                const float (&dy)[P], const float (&dz)[P], const float (&aa)[P],
+                                                float (&best_t)[P], int (&best_obj)[P], int (&best_prim)[P])
+{
+  for (int j0 = 0; j0 < padded; j0 += US) {
+    float4 cur[US];
+#pragma unroll
+    for (int k = 0; k < US; ++k) cur[k] = rec[j0 + k];
+    float b[US][P], disc[US][P];
+    float dmax = -MRT_INF; // max ignores NaN discriminants, which can never be hits
+#pragma unroll
+    for (int k = 0; k < US; ++k) {
+#pragma unroll
+      for (int p = 0; p < P; ++p) {
+        b[k][p] = dot3(cur[k].x, cur[k].y, cur[k].z, dx[p], dy[p], dz[p]);
+        disc[k][p] = b[k][p] * b[k][p] - aa[p] * cur[k].w;
+        dmax = fmaxf(dmax, disc[k][p]);
+      }
+    }
+    const bool cand = dmax >= 0.0f;
+    if (cand) {
+#pragma unroll
+      for (int k = 0; k < US; ++k) {
+        bool ck = false;
+#pragma unroll
+        for (int p = 0; p < P; ++p) ck |= (disc[k][p] >= 0.0f);
+        if (ck) {
+          const int obj = sph_obj[prim0 + j0 + k];
+#pragma unroll
+          for (int p = 0; p < P; ++p) {
+            if (disc[k][p] >= 0.0f) {
+              float t;
+              if (sphere_roots(aa[p], b[k][p], disc[k][p], 0.01f, MRT_INF, t)) {
+                if (t < best_t[p] || (t == best_t[p] && t < MRT_INF && obj < best_obj[p])) {
+                  best_t[p] = t; best_obj[p] = obj; best_prim[p] = prim0 + j0 + k;
+                }
+              }
+            }
+          }
+        }
+      }
+    }
+  }
+}
+
+// closest hit over one chunk of triangle records (core/triangle.cuh:77-103); the rays share the origin o
+template <int P>
+__device__ __forceinline__ void closest_triangles(const LdsPlan &L, int padded, int prim0,
+                                                  const int32_t *__restrict__ tri_obj, float ox, float oy, float oz,
+                                                  const float (&dx)[P], const float (&dy)[P], const float (&dz)[P],
+                                                  float (&best_t)[P], int (&best_obj)[P], int (&best_prim)[P])
+{
+  for (int j0 = 0; j0 < padded; j0 += UT) {
+    Tri cur[UT];
+#pragma unroll
+    for (int k = 0; k < UT; ++k) cur[k] = load_tri(L, j0 + k);
+    float t[UT][P];
+    bool hit[UT][P];
+    bool any = false;
+#pragma unroll
+    for (int k = 0; k < UT; ++k) {
+      const Tri &T = cur[k];
+#pragma unroll
+      for (int p = 0; p < P; ++p) {
+        float rdn = dot3(dx[p], dy[p], dz[p], T.q0.x, T.q0.y, T.q0.z);
+        t[k][p] = T.num / rdn;
+        float px = ox + t[k][p] * dx[p], py = oy + t[k][p] * dy[p], pz = oz + t[k][p] * dz[p];
+        float e0 = dot3(T.q1.x, T.q1.y, T.q1.z, px, py, pz) - T.q1.w;
+        float e1 = dot3(T.q2.x, T.q2.y, T.q2.z, px, py, pz) - T.q2.w;
+        float e2 = dot3(T.q3.x, T.q3.y, T.q3.z, px, py, pz) - T.q3.w;
+        hit[k][p] = (rdn != 0.0f) & (e0 > -1e-6f) & (e1 > -1e-6f) & (e2 > -1e-6f) & (0.01f <= t[k][p]) &
+                    (t[k][p] <= MRT_INF);
+        any |= hit[k][p];
+      }
+    }
+    if (any) {
+#pragma unroll
+      for (int k = 0; k < UT; ++k) {
+        bool hk = false;
+#pragma unroll
+        for (int p = 0; p < P; ++p) hk |= hit[k][p];
+        if (hk) {
+          const int obj = tri_obj[prim0 + j0 + k];
+#pragma unroll
+          for (int p = 0; p < P; ++p) {
+            if (hit[k][p] &&
+                (t[k][p] < best_t[p] || (t[k][p] == best_t[p] && t[k][p] < MRT_INF && obj < best_obj[p]))) {
+              best_t[p] = t[k][p]; best_obj[p] = obj; best_prim[p] = prim0 + j0 + k;
+            }
+          }
+        }
+      }
+    }
+  }
+}
+
+// Shadow-ray directions: one per wave for a directional light, one per lane for a point light.
+template <int P> struct UniformDir {
+  float x, y, z, a, tl;
+  __device__ __forceinline__ float dx(int) const { return x; }
+  __device__ __forceinline__ float dy(int) const { return y; }
+  __device__ __forceinline__ float dz(int) const { return z; }
+  __device__ __forceinline__ float da(int) const { return a; }
+  __device__ __forceinline__ float tmax(int) const { return tl; }
+};
+template <int P> struct LaneDir {
+  float x[P], y[P], z[P], a[P];
+  __device__ __forceinline__ float dx(int p) const { return x[p]; }
+  __device__ __forceinline__ float dy(int p) const { return y[p]; }
+  __device__ __forceinline__ float dz(int p) const { return z[p]; }
+  __device__ __forceinline__ float da(int p) const { return a[p]; }
+  __device__ __forceinline__ float tmax(int) const { return 1.0f; } // PointLight: t_light = 1 (core/light.cuh:50)
+};
+
+// any-hit over one chunk of sphere shadow records, interval [1e-3, t_light] (core/light.cuh:28-33).
+// Returns false once no lane of the wave has an undecided ray left (ballot early-out).
+template <int P, class D>
+__device__ __forceinline__ bool occlude_spheres(const float4 *__restrict__ rec, int padded, const D &d,
+                                                const float (&hx)[P], const float (&hy)[P], const float (&hz)[P],
+                                                bool (&open)[P])
+{
+  for (int j0 = 0; j0 < padded; j0 += US) {
+    float4 cur[US];
+#pragma unroll
+    for (int k = 0; k < US; ++k) cur[k] = rec[j0 + k];
+    float b[US][P], disc[US][P];
+    float dmax[P];
+#pragma unroll
+    for (int p = 0; p < P; ++p) dmax[p] = -MRT_INF;
+#pragma unroll
+    for (int k = 0; k < US; ++k) {
+#pragma unroll
+      for (int p = 0; p < P; ++p) {
+        float ocx = hx[p] - cur[k].x, ocy = hy[p] - cur[k].y, ocz = hz[p] - cur[k].z;
+        b[k][p] = dot3(ocx, ocy, ocz, d.dx(p), d.dy(p), d.dz(p));
+        float c = dot3(ocx, ocy, ocz, ocx, ocy, ocz) - cur[k].w;
+        disc[k][p] = b[k][p] * b[k][p] - d.da(p) * c;
+        dmax[p] = fmaxf(dmax[p], disc[k][p]);
+      }
+    }
+    bool cand = false;
+#pragma unroll
+    for (int p = 0; p < P; ++p) cand |= open[p] && (dmax[p] >= 0.0f);
+    if (cand) {
+#pragma unroll
+      for (int k = 0; k < US; ++k) {
+#pragma unroll
+        for (int p = 0; p < P; ++p) {
+          if (open[p] && disc[k][p] >= 0.0f) {
+            float t;
+            if (sphere_roots(d.da(p), b[k][p], disc[k][p], 1e-3f, d.tmax(p), t)) open[p] = false;
+          }
+        }
+      }
+      bool still = false;
+#pragma unroll
+      for (int p = 0; p < P; ++p) still |= open[p];
+      if (!__any(still)) return false;
+    }
+  }
+  return true;
+}
+
+template <int P, class D>
+__device__ __forceinline__ bool occlude_triangles(const LdsPlan &L, int padded, const D &d, const float (&hx)[P],
+                                                  const float (&hy)[P], const float (&hz)[P], bool (&open)[P])
+{
+  for (int j0 = 0; j0 < padded; j0 += UT) {
+    Tri cur[UT];
+#pragma unroll
+    for (int k = 0; k < UT; ++k) cur[k] = load_tri(L, j0 + k);
+    bool blocked = false;
+#pragma unroll
+    for (int k = 0; k < UT; ++k) {
+      const Tri &T = cur[k];
+#pragma unroll
+      for (int p = 0; p < P; ++p) {
+        float rdn = dot3(d.dx(p), d.dy(p), d.dz(p), T.q0.x, T.q0.y, T.q0.z);
+        float t = (T.q0.w - dot3(hx[p], hy[p], hz[p], T.q0.x, T.q0.y, T.q0.z)) / rdn;
+        float px = hx[p] + t * d.dx(p), py = hy[p] + t * d.dy(p), pz = hz[p] + t * d.dz(p);
+        float e0 = dot3(T.q1.x, T.q1.y, T.q1.z, px, py, pz) - T.q1.w;
+        float e1 = dot3(T.q2.x, T.q2.y, T.q2.z, px, py, pz) - T.q2.w;
+        float e2 = dot3(T.q3.x, T.q3.y, T.q3.z, px, py, pz) - T.q3.w;
+        bool h = (rdn != 0.0f) & (e0 > -1e-6f) & (e1 > -1e-6f) & (e2 > -1e-6f) & (1e-3f <= t) & (t <= d.tmax(p));
+        if (open[p] && h) { open[p] = false; blocked = true; }
+      }
+    }
+    if (__any(blocked)) {
+      bool still = false;
+#pragma unroll
+      for (int p = 0; p < P; ++p) still |= open[p];
+      if (!__any(still)) return false;
+    }
+  }
+  return true;
+}
+
+// One light's occlusion pass over the whole scene.  Streaming scenes restage every chunk, so all
+// waves of the workgroup walk the chunk loops together (barriers) even when they have nothing left.
+template <int P, class D>
+__device__ __forceinline__ void occlusion_pass(const RenderArgs &A, const LdsPlan &L, const D &d,
+                                               const float (&hx)[P], const float (&hy)[P], const float (&hz)[P],
+                                               bool (&open)[P])
+{
+  const DevScene &sc = A.sc;
+  bool live = false;
+#pragma unroll
+  for (int p = 0; p < P; ++p) live |= open[p];
+  bool wave_live = __any(live);
+  for (int c0 = 0; c0 < sc.ns; c0 += A.s_cap) {
+    const int cnt = min(A.s_cap, sc.ns - c0);
+    if (!A.resident) {
+      __syncthreads();
+      stage_spheres(sc, A.cam, L, c0, cnt, 2);
+      __syncthreads();
+    }
+    if (wave_live) wave_live = occlude_spheres<P>(L.sphS, round_up(cnt, US), d, hx, hy, hz, open);
+  }
+  for (int c0 = 0; c0 < sc.nt; c0 += A.t_cap) {
+    const int cnt = min(A.t_cap, sc.nt - c0);
+    if (!A.resident) {
+      __syncthreads();
+      stage_triangles(sc, A.cam, L, c0, cnt);
+      __syncthreads();
+    }
+    if (wave_live) wave_live = occlude_triangles<P>(L, round_up(cnt, UT), d, hx, hy, hz, open);
   }
 }
 
@@ -145,13 +420,8 @@ __global__ __launch_bounds__(256) void render_kernel(RenderArgs A)
   }
 
   bool valid[P];
-  float u[P];
 #pragma unroll
-  for (int p = 0; p < P; ++p) {
-    int col = col0 + p;
-    valid[p] = row_ok && (col < A.W);
-    u[p] = float(col) / float(A.W);     // src/main.cu:136
-  }
+  for (int p = 0; p < P; ++p) valid[p] = row_ok && (col0 + p < A.W);
   const float v = float(grow) / float(A.H); // src/main.cu:137
 
   float accr[P], accg[P], accb[P];
@@ -180,8 +450,8 @@ __global__ __launch_bounds__(256) void render_kernel(RenderArgs A)
     int best_obj[P], best_prim[P];
 #pragma unroll
     for (int p = 0; p < P; ++p) {
-      float su = u[p], sv = v;
-      if (nsamp > 1) { su = u[p] + offx; sv = v + offy; }
+      float su = float(col0 + p) / float(A.W), sv = v; // src/main.cu:136
+      if (nsamp > 1) { su = su + offx; sv = v + offy; }
       dx[p] = ((cam.ux + su * cam.hx) + sv * cam.vx) - cam.ox;
       dy[p] = ((cam.uy + su * cam.hy) + sv * cam.vy) - cam.oy;
       dz[p] = ((cam.uz + su * cam.hz) + sv * cam.vz) - cam.oz;
@@ -191,7 +461,7 @@ __global__ __launch_bounds__(256) void render_kernel(RenderArgs A)
       best_prim[p] = -1;
     }
 
-    // ---- closest hit over spheres (src/main.cu:60-77 + core/sphere.cuh:32-73), interval [0.01, inf] ----
+    // ---- closest hit, interval [0.01, inf] ----
     for (int c0 = 0; c0 < ns; c0 += A.s_cap) {
       const int cnt = min(A.s_cap, ns - c0);
       if (!A.resident) {
@@ -199,34 +469,8 @@ __global__ __launch_bounds__(256) void render_kernel(RenderArgs A)
         stage_spheres(sc, cam, L, c0, cnt, 1);
         __syncthreads();
       }
-      for (int j = 0; j < cnt; ++j) {
-        const float4 s = L.sphP[j]; // oc.xyz, oc.oc - r*r
-        float b[P], disc[P];
-        bool cand = false;
-#pragma unroll
-        for (int p = 0; p < P; ++p) {
-          b[p] = dot3(s.x, s.y, s.z, dx[p], dy[p], dz[p]);
-          disc[p] = b[p] * b[p] - aa[p] * s.w;
-          cand |= (disc[p] >= 0.0f);
-        }
-        if (cand) {
-          const int obj = sc.sph_obj[c0 + j];
-#pragma unroll
-          for (int p = 0; p < P; ++p) {
-            if (disc[p] >= 0.0f) {
-              float t;
-              if (sphere_roots(aa[p], b[p], disc[p], 0.01f, MRT_INF, t)) {
-                if (t < best_t[p] || (t == best_t[p] && t < MRT_INF && obj < best_obj[p])) {
-                  best_t[p] = t; best_obj[p] = obj; best_prim[p] = c0 + j;
-                }
-              }
-            }
-          }
-        }
-      }
+      closest_spheres<P>(L.sphP, round_up(cnt, US), c0, sc.sph_obj, dx, dy, dz, aa, best_t, best_obj, best_prim);
     }
-
-    // ---- closest hit over triangles (core/triangle.cuh:77-103) ----
     for (int c0 = 0; c0 < nt; c0 += A.t_cap) {
       const int cnt = min(A.t_cap, nt - c0);
       if (!A.resident) {
@@ -234,33 +478,8 @@ __global__ __launch_bounds__(256) void render_kernel(RenderArgs A)
         stage_triangles(sc, cam, L, c0, cnt);
         __syncthreads();
       }
-      for (int j = 0; j < cnt; ++j) {
-        const float4 q0 = L.tri[4 * j + 0], q1 = L.tri[4 * j + 1], q2 = L.tri[4 * j + 2], q3 = L.tri[4 * j + 3];
-        const float num = L.triNum[j];
-        float t[P];
-        bool hit[P];
-        bool any = false;
-#pragma unroll
-        for (int p = 0; p < P; ++p) {
-          float rdn = dot3(dx[p], dy[p], dz[p], q0.x, q0.y, q0.z);
-          t[p] = num / rdn;
-          float px = cam.ox + t[p] * dx[p], py = cam.oy + t[p] * dy[p], pz = cam.oz + t[p] * dz[p];
-          float e0 = dot3(q1.x, q1.y, q1.z, px, py, pz) - q1.w;
-          float e1 = dot3(q2.x, q2.y, q2.z, px, py, pz) - q2.w;
-          float e2 = dot3(q3.x, q3.y, q3.z, px, py, pz) - q3.w;
-          hit[p] = (rdn != 0.0f) & (e0 > -1e-6f) & (e1 > -1e-6f) & (e2 > -1e-6f) & (0.01f <= t[p]) & (t[p] <= MRT_INF);
-          any |= hit[p];
-        }
-        if (any) {
-          const int obj = sc.tri_obj[c0 + j];
-#pragma unroll
-          for (int p = 0; p < P; ++p) {
-            if (hit[p] && (t[p] < best_t[p] || (t[p] == best_t[p] && t[p] < MRT_INF && obj < best_obj[p]))) {
-              best_t[p] = t[p]; best_obj[p] = obj; best_prim[p] = ns + c0 + j;
-            }
-          }
-        }
-      }
+      closest_triangles<P>(L, round_up(cnt, UT), ns + c0, sc.tri_obj - ns, cam.ox, cam.oy, cam.oz, dx, dy, dz, best_t,
+                           best_obj, best_prim);
     }
 
     // ---- hit record of the winner: point, normal (core/sphere.cuh:45-47, core/triangle.cuh:96-97) ----
@@ -299,127 +518,72 @@ __global__ __launch_bounds__(256) void render_kernel(RenderArgs A)
 #pragma unroll
     for (int p = 0; p < P; ++p) { lr[p] = lg[p] = lb[p] = 0.0f; have_light[p] = false; }
 
-    // Streaming scenes restage per light, so every wave of the workgroup must walk the
-    // light loop together; resident scenes let a wave with no hit skip it.
+    // Resident scenes let a wave with no hit skip the light loop; streaming scenes cannot (barriers).
     if (!A.resident || wave_any_hit) {
       for (int li = 0; li < sc.nl; ++li) {
         const int lkind = sc.light_kind[li];
         const float lvx = sc.light_vec[3 * li], lvy = sc.light_vec[3 * li + 1], lvz = sc.light_vec[3 * li + 2];
-        float sdx[P], sdy[P], sdz[P], sa[P], tl[P], lnx[P], lny[P], lnz[P];
-        bool need[P];
-        bool any_need = false;
+        const float lcr = sc.light_rgb[3 * li], lcg = sc.light_rgb[3 * li + 1], lcb = sc.light_rgb[3 * li + 2];
+        bool need[P], open[P];
+        float scale[P], refl_dot[P]; // inputs of light_bounce, see below
+
+        if (lkind == 0) {
+          // DirectionalLight::ray_from, core/light.cuh:73-81: ray {point, -dir}, t = inf, light normal = dir
+          UniformDir<P> d;
+          d.x = -lvx; d.y = -lvy; d.z = -lvz; d.tl = MRT_INF;
+          d.a = dot3(d.x, d.y, d.z, d.x, d.y, d.z);
 #pragma unroll
-        for (int p = 0; p < P; ++p) {
-          if (lkind == 0) { // DirectionalLight::ray_from, core/light.cuh:73-81
-            sdx[p] = -lvx; sdy[p] = -lvy; sdz[p] = -lvz;
-            tl[p] = MRT_INF;
-            lnx[p] = lvx; lny[p] = lvy; lnz[p] = lvz;
-          } else {          // PointLight::ray_from, core/light.cuh:47-53
-            sdx[p] = lvx - hpx[p]; sdy[p] = lvy - hpy[p]; sdz[p] = lvz - hpz[p];
-            tl[p] = 1.0f;
+          for (int p = 0; p < P; ++p) {
+            // the light must not shine through the surface, core/light.cuh:148
+            need[p] = have_hit[p] && !(dot3(d.x, d.y, d.z, hnx[p], hny[p], hnz[p]) < 0);
+            open[p] = need[p];
+          }
+          occlusion_pass<P>(A, L, d, hpx, hpy, hpz, open);
+          // light_bounce gets the LIGHT's normal (= dir), as the reference passes it (core/light.cuh:164-168)
+          const float dn = dot3(d.x, d.y, d.z, lvx, lvy, lvz);
+          const float s2 = 2.0f * dn;
+          const float rx = d.x - s2 * lvx, ry = d.y - s2 * lvy, rz = d.z - s2 * lvz;
+#pragma unroll
+          for (int p = 0; p < P; ++p) {
+            scale[p] = -dn;
+            refl_dot[p] = dot3(rx, ry, rz, dx[p], dy[p], dz[p]);
+          }
+        } else {
+          // PointLight::ray_from, core/light.cuh:47-53: ray {point, pos - point}, t = 1,
+          // light normal = (point - pos).normalized()
+          LaneDir<P> d;
+          float lnx[P], lny[P], lnz[P];
+#pragma unroll
+          for (int p = 0; p < P; ++p) {
+            d.x[p] = lvx - hpx[p]; d.y[p] = lvy - hpy[p]; d.z[p] = lvz - hpz[p];
+            d.a[p] = dot3(d.x[p], d.y[p], d.z[p], d.x[p], d.y[p], d.z[p]);
             float nx = hpx[p] - lvx, ny = hpy[p] - lvy, nz = hpz[p] - lvz;
             normalize3(nx, ny, nz);
             lnx[p] = nx; lny[p] = ny; lnz[p] = nz;
+            need[p] = have_hit[p] && !(dot3(d.x[p], d.y[p], d.z[p], hnx[p], hny[p], hnz[p]) < 0);
+            open[p] = need[p];
           }
-          sa[p] = dot3(sdx[p], sdy[p], sdz[p], sdx[p], sdy[p], sdz[p]);
-          // light must not shine through the surface, core/light.cuh:148
-          need[p] = have_hit[p] && !(dot3(sdx[p], sdy[p], sdz[p], hnx[p], hny[p], hnz[p]) < 0);
-          if (need[p] && valid[p]) n_shadow++;
-          any_need |= need[p];
-        }
-        bool open[P]; // still un-occluded
+          occlusion_pass<P>(A, L, d, hpx, hpy, hpz, open);
 #pragma unroll
-        for (int p = 0; p < P; ++p) open[p] = need[p];
-
-        // any-hit over spheres, interval [1e-3, t_light] (core/light.cuh:28-33)
-        for (int c0 = 0; c0 < ns; c0 += A.s_cap) {
-          const int cnt = min(A.s_cap, ns - c0);
-          if (!A.resident) {
-            __syncthreads();
-            stage_spheres(sc, cam, L, c0, cnt, 2);
-            __syncthreads();
-          }
-          bool live = false;
-#pragma unroll
-          for (int p = 0; p < P; ++p) live |= open[p];
-          if (!__any(live)) continue; // ballot early-out: nothing left to decide in this wave
-          for (int j = 0; j < cnt; ++j) {
-            const float4 s = L.sphS[j]; // c.xyz, r*r
-            float b[P], disc[P];
-            bool cand = false;
-#pragma unroll
-            for (int p = 0; p < P; ++p) {
-              float ocx = hpx[p] - s.x, ocy = hpy[p] - s.y, ocz = hpz[p] - s.z;
-              b[p] = dot3(ocx, ocy, ocz, sdx[p], sdy[p], sdz[p]);
-              float c = dot3(ocx, ocy, ocz, ocx, ocy, ocz) - s.w;
-              disc[p] = b[p] * b[p] - sa[p] * c;
-              cand |= open[p] && (disc[p] >= 0.0f);
-            }
-            if (cand) {
-              bool still = false;
-#pragma unroll
-              for (int p = 0; p < P; ++p) {
-                if (open[p] && disc[p] >= 0.0f) {
-                  float t;
-                  if (sphere_roots(sa[p], b[p], disc[p], 1e-3f, tl[p], t)) open[p] = false;
-                }
-                still |= open[p];
-              }
-              if (!__any(still)) break;
-            }
-          }
-        }
-        // any-hit over triangles
-        for (int c0 = 0; c0 < nt; c0 += A.t_cap) {
-          const int cnt = min(A.t_cap, nt - c0);
-          if (!A.resident) {
-            __syncthreads();
-            stage_triangles(sc, cam, L, c0, cnt);
-            __syncthreads();
-          }
-          bool live = false;
-#pragma unroll
-          for (int p = 0; p < P; ++p) live |= open[p];
-          if (!__any(live)) continue;
-          for (int j = 0; j < cnt; ++j) {
-            const float4 q0 = L.tri[4 * j + 0], q1 = L.tri[4 * j + 1], q2 = L.tri[4 * j + 2], q3 = L.tri[4 * j + 3];
-            bool blocked = false;
-#pragma unroll
-            for (int p = 0; p < P; ++p) {
-              float rdn = dot3(sdx[p], sdy[p], sdz[p], q0.x, q0.y, q0.z);
-              float t = (q0.w - dot3(hpx[p], hpy[p], hpz[p], q0.x, q0.y, q0.z)) / rdn;
-              float px = hpx[p] + t * sdx[p], py = hpy[p] + t * sdy[p], pz = hpz[p] + t * sdz[p];
-              float e0 = dot3(q1.x, q1.y, q1.z, px, py, pz) - q1.w;
-              float e1 = dot3(q2.x, q2.y, q2.z, px, py, pz) - q2.w;
-              float e2 = dot3(q3.x, q3.y, q3.z, px, py, pz) - q3.w;
-              bool h = (rdn != 0.0f) & (e0 > -1e-6f) & (e1 > -1e-6f) & (e2 > -1e-6f) & (1e-3f <= t) & (t <= tl[p]);
-              if (open[p] && h) { open[p] = false; blocked = true; }
-            }
-            if (__any(blocked)) {
-              bool still = false;
-#pragma unroll
-              for (int p = 0; p < P; ++p) still |= open[p];
-              if (!__any(still)) break;
-            }
+          for (int p = 0; p < P; ++p) {
+            const float dn = dot3(d.x[p], d.y[p], d.z[p], lnx[p], lny[p], lnz[p]);
+            const float s2 = 2.0f * dn;
+            const float rx = d.x[p] - s2 * lnx[p], ry = d.y[p] - s2 * lny[p], rz = d.z[p] - s2 * lnz[p];
+            scale[p] = -dn;
+            refl_dot[p] = dot3(rx, ry, rz, dx[p], dy[p], dz[p]);
           }
         }
 
-        // light_bounce with the LIGHT's normal, as the reference passes it (core/light.cuh:164-168)
-        const float lcr = sc.light_rgb[3 * li], lcg = sc.light_rgb[3 * li + 1], lcb = sc.light_rgb[3 * li + 2];
 #pragma unroll
         for (int p = 0; p < P; ++p) {
-          if (need[p] && !open[p] && valid[p]) n_occl++;
+          if (need[p] && valid[p]) { n_shadow++; if (!open[p]) n_occl++; }
           if (open[p]) {
             float cr, cg, cb;
-            const int mk = sc.mat_kind[best_obj[p]];
-            if (mk == 0) { // DiffuseMaterial::light_bounce, core/material.cuh:63-75
-              float scale = -dot3(sdx[p], sdy[p], sdz[p], lnx[p], lny[p], lnz[p]);
-              if (scale > 0.0f) { cr = scale * lcr; cg = scale * lcg; cb = scale * lcb; }
+            if (sc.mat_kind[best_obj[p]] == 0) { // DiffuseMaterial::light_bounce, core/material.cuh:63-75
+              if (scale[p] > 0.0f) { cr = scale[p] * lcr; cg = scale[p] * lcg; cb = scale[p] * lcb; }
               else { cr = 0.0f; cg = 0.0f; cb = 0.0f; }
-            } else {       // MetallicMaterial::light_bounce, core/material.cuh:134-158
-              float s2 = 2.0f * dot3(sdx[p], sdy[p], sdz[p], lnx[p], lny[p], lnz[p]);
-              float rx = sdx[p] - s2 * lnx[p], ry = sdy[p] - s2 * lny[p], rz = sdz[p] - s2 * lnz[p];
-              if (dot3(rx, ry, rz, dx[p], dy[p], dz[p]) < -0.99f) { cr = lcr; cg = lcg; cb = lcb; }
+            } else {                             // MetallicMaterial::light_bounce, core/material.cuh:134-158
+              if (refl_dot[p] < -0.99f) { cr = lcr; cg = lcg; cb = lcb; }
               else { cr = 0.001f; cg = 0.001f; cb = 0.001f; }
             }
             if (have_light[p]) { lr[p] += cr; lg[p] += cg; lb[p] += cb; }
@@ -485,27 +649,33 @@ __global__ __launch_bounds__(256) void render_kernel(RenderArgs A)
 }
 
 static size_t lds_bytes(int s_cap, int t_cap) { return size_t(2 * s_cap + 4 * t_cap) * 16 + size_t(t_cap) * 4; }
+static int round_up_h(int x, int m) { return (x + m - 1) / m * m; }
 
 hipError_t launch_render(const RenderArgs &in, hipStream_t stream)
 {
   RenderArgs A = in;
   const int ns = A.sc.ns, nt = A.sc.nt;
   // resident when the whole scene (both sphere records + triangle records) fits in 48 KiB
-  const size_t need = lds_bytes(ns, nt);
-  if (need <= 48 * 1024) {
+  const int ns_pad = round_up_h(ns > 0 ? ns : 1, US), nt_pad = round_up_h(nt > 0 ? nt : 1, UT);
+  if (lds_bytes(ns_pad, nt_pad) <= 48 * 1024) {
     A.resident = 1;
-    A.s_cap = ns > 0 ? ns : 1;
-    A.t_cap = nt > 0 ? nt : 1;
+    A.s_cap = ns_pad;
+    A.t_cap = nt_pad;
   } else {
     A.resident = 0;
     A.s_cap = 512;  // 2 x 8 KiB sphere records
     A.t_cap = 256;  // 16 KiB triangle records + 1 KiB numerators
   }
   const size_t lds = lds_bytes(A.s_cap, A.t_cap);
-  constexpr int P = 4;
+  static const int forced_p = [] { const char *e = getenv("MRT_PIXELS_PER_LANE"); return e ? atoi(e) : 0; }();
+  const int P = forced_p ? forced_p : 1;
   dim3 grid((A.W + 32 * P - 1) / (32 * P), (A.local_rows + 7) / 8);
   if (grid.x == 0 || grid.y == 0) return hipSuccess;
-  hipLaunchKernelGGL(render_kernel<P>, grid, dim3(256), lds, stream, A);
+  switch (P) {
+  case 1: hipLaunchKernelGGL(render_kernel<1>, grid, dim3(256), lds, stream, A); break;
+  case 2: hipLaunchKernelGGL(render_kernel<2>, grid, dim3(256), lds, stream, A); break;
+  default: hipLaunchKernelGGL(render_kernel<4>, grid, dim3(256), lds, stream, A); break;
+  }
   return hipGetLastError();
 }
 

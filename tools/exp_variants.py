@@ -1,0 +1,34 @@
+"""Experiment: kernel time of the C2 frame under different env-selected kernel variants."""
+import sys, os, time, subprocess, json
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+if len(sys.argv) > 1 and sys.argv[1] == "child":
+    import torch
+    from raytracing_amd import capi, scenes, multigpu
+    cfg = sys.argv[2]
+    if cfg == "C2":
+        flat, cam = scenes.default_scene(); W, H = 1920, 1080
+        cam12 = capi.viewport(cam["look_from"], cam["look_at"], cam["up"], cam["vfov"], W / H)
+    else:
+        spec = {"C3": lambda: scenes.sphere_field(10000), "C5": scenes.light_stress,
+                "C4s": lambda: scenes.triangle_terrain(100, 50)}[cfg]()
+        W, H = (3840, 2160) if cfg == "C3" else (1920, 1080)
+        flat = spec.flatten(); cam12 = spec.cam12(W / H)
+    fr = multigpu.FrameRenderer(flat, cam12, W, H, with_ids=True)
+    n = 200 if cfg == "C2" else 5
+    for _ in range(max(2, n // 10)): fr.render_local()
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(n): fr.render_local()
+    torch.cuda.synchronize()
+    print(json.dumps({"us_per_frame": (time.perf_counter() - t0) / n * 1e6}))
+    sys.exit(0)
+cfgs = sys.argv[1].split(",") if len(sys.argv) > 1 else ["C2"]
+variants = [v for v in (sys.argv[2].split(";") if len(sys.argv) > 2 else [""])]
+for cfg in cfgs:
+    for v in variants:
+        env = dict(os.environ)
+        for kv in v.split(","):
+            if kv: k, val = kv.split("="); env[k] = val
+        out = subprocess.run([sys.executable, __file__, "child", cfg], env=env, capture_output=True, text=True)
+        line = [l for l in out.stdout.splitlines() if l.startswith("{")]
+        print(cfg, v or "default", line[-1] if line else out.stderr[-300:], flush=True)
