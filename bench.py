@@ -56,6 +56,22 @@ def build_workload(name):
     return flat, cam12, W, H, flops, scene_bytes, spec, label
 
 
+def measured_traffic(config, alg_bytes):
+    """HBM bytes per launch from the committed PMC passes (profiles/hbm_traffic.json, produced by
+    tools/pmc_bench.sh: FETCH_SIZE and WRITE_SIZE in separate rocprofv3 --pmc runs of this command).
+    gfx950 correction from MI355X_MICROARCH.md: FETCH_SIZE counts half the bytes of wide reads -> x2;
+    both counters are in KiB."""
+    path = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+    try:
+        with open(path) as f:
+            t = json.load(f).get(config)
+        if not t:
+            return None
+        return int((2.0 * t["FETCH_SIZE_KB"] + t["WRITE_SIZE_KB"]) * 1024)
+    except (OSError, ValueError, KeyError):
+        return None
+
+
 def cpu_baseline(name, spec, cam12, W, H, total_rays_full):
     """Time the CPU oracle (a scalar port of the reference path) on this host: bounded sample."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -186,7 +202,8 @@ def main():
                                       ("" if world == 1 else ", RCCL gather to rank 0 + strip assembly"),
                        "outputs": "rgb f32 + id i32 + t f32" if not args.no_ids else "rgb f32"},
             "roofline": {"bound": "hbm", "achieved": round(ach_gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(ach_gbs / HBM_PEAK_GBS, 5), "traffic": None,
+                         "frac": round(ach_gbs / HBM_PEAK_GBS, 5),
+                         "traffic": measured_traffic(args.config, alg_bytes) if world == 1 else None,
                          "kernel": "render_kernel", "kernel_ms": round(kern_ms, 5),
                          "algorithmic_bytes_per_launch": alg_bytes},
             "roofline_valu": {"bound": "fp32 vector ALU (no MFMA: no dense contraction)",
