@@ -120,6 +120,14 @@ int mrt_ctx_destroy(mrt_ctx *ctx);
 const char *mrt_last_error(const mrt_ctx *ctx);
 const char *mrt_status_string(int status);
 
+/*
+ * Context options (no reference counterpart).  MRT_OPT_CULL: 1 (default, or environment MRT_CULL) renders
+ * with the tile-culling kernel; 0 with the brute-force kernel that, like the reference loops
+ * (src/main.cu:67-77), tests every ray against every primitive.  Both produce identical buffers.
+ */
+enum { MRT_OPT_CULL = 1 };
+int mrt_ctx_set_option(mrt_ctx *ctx, int option, int value);
+
 /* --- scene: replaces cudaMallocManaged-backed rt::Vector (container/vector.cuh:26,131) */
 int mrt_scene_upload(mrt_ctx *ctx, const mrt_scene_desc *scene);
 

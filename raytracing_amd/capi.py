@@ -18,7 +18,7 @@ LIGHT_DIRECTIONAL, LIGHT_POINT = 0, 1
 
 # every symbol include/mrt.h declares (tests check the library exports all of them)
 MRT_SYMBOLS = [
-    "mrt_device_count", "mrt_ctx_create", "mrt_ctx_destroy", "mrt_last_error", "mrt_status_string",
+    "mrt_device_count", "mrt_ctx_create", "mrt_ctx_destroy", "mrt_ctx_set_option", "mrt_last_error", "mrt_status_string",
     "mrt_scene_upload", "mrt_local_rows", "mrt_render", "mrt_render_device", "mrt_assemble_strips",
     "mrt_intersect",
 ]
@@ -90,6 +90,7 @@ def libmrt():
         L.mrt_device_count.argtypes = [C.POINTER(C.c_int)]
         L.mrt_ctx_create.argtypes = [C.c_int, C.POINTER(C.c_void_p)]
         L.mrt_ctx_destroy.argtypes = [C.c_void_p]
+        L.mrt_ctx_set_option.argtypes = [C.c_void_p, C.c_int, C.c_int]
         L.mrt_last_error.argtypes = [C.c_void_p]
         L.mrt_last_error.restype = C.c_char_p
         L.mrt_status_string.argtypes = [C.c_int]
@@ -294,6 +295,10 @@ class Context:
         if rc != 0:
             raise MrtError(f"{what}: {rc} ({self._L.mrt_status_string(rc).decode()}) "
                            f"{self._L.mrt_last_error(self._h).decode()}")
+
+    def set_cull(self, on):
+        """True: tile-culling kernel (default); False: brute-force kernel.  Identical outputs."""
+        self._check(self._L.mrt_ctx_set_option(self._h, 1, 1 if on else 0), "mrt_ctx_set_option")
 
     def upload(self, flat):
         d = flat.desc()

@@ -11,6 +11,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -32,6 +33,7 @@ struct mrt_ctx {
   void *out_mem = nullptr;
   size_t out_bytes = 0;
   unsigned long long *stats_dev = nullptr;
+  bool cull = true;
 };
 
 static thread_local std::string g_create_err;
@@ -55,7 +57,22 @@ static int hip_fail(mrt_ctx *ctx, hipError_t e, const char *what)
     if (e_ != hipSuccess) return hip_fail((ctx), e_, #expr); \
   } while (0)
 
+// MRT_CULL=0 selects the brute-force LDS kernel (every ray x every primitive); the default kernel culls
+// primitives per tile first and produces identical buffers (tests compare the two).
+static bool use_cull()
+{
+  static const bool v = [] { const char *e = getenv("MRT_CULL"); return !(e && e[0] == '0'); }();
+  return v;
+}
+
 extern "C" {
+
+int mrt_ctx_set_option(mrt_ctx *ctx, int option, int value)
+{
+  if (!ctx) return MRT_ERR_INVALID;
+  if (option == MRT_OPT_CULL) { ctx->cull = value != 0; return MRT_OK; }
+  return fail(ctx, MRT_ERR_INVALID, "unknown option");
+}
 
 const char *mrt_status_string(int status)
 {
@@ -93,6 +110,7 @@ int mrt_ctx_create(int device, mrt_ctx **out)
   mrt_ctx *ctx = new (std::nothrow) mrt_ctx();
   if (!ctx) return fail(nullptr, MRT_ERR_INVALID, "out of host memory");
   ctx->device = device;
+  ctx->cull = use_cull();
   auto bail = [&](hipError_t err, const char *what) {
     int rc = hip_fail(nullptr, err, what);
     mrt_ctx_destroy(ctx);
@@ -123,6 +141,67 @@ int mrt_ctx_destroy(mrt_ctx *ctx)
 }
 
 static size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+// Conservative bounding sphere of the region Triangle::hit accepts (core/triangle.cuh:89-91): the set of
+// points p with n_i.p - k_i > -1e-6 for the three edge planes, near the plane pn.p = kp.  Derived from the
+// 16 precomputed floats only (the hit test never sees vertices, and for degenerate triangles -- e.g. a
+// plane through the world origin, SURVEY section 0.6 -- the accepted region is NOT the geometric triangle).
+// Unbounded, empty or ill-conditioned regions get radius +inf, i.e. are never culled.
+static void tri_bound(const float q[16], float out[4])
+{
+  out[0] = out[1] = out[2] = 0.0f;
+  out[3] = INFINITY;
+  double pn[3] = {q[0], q[1], q[2]}, kp = q[3], n[3][3], k[3];
+  for (int i = 0; i < 3; ++i) { n[i][0] = q[4 + 4 * i]; n[i][1] = q[5 + 4 * i]; n[i][2] = q[6 + 4 * i]; k[i] = q[7 + 4 * i]; }
+  auto norm = [](const double v[3]) { return std::sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]); };
+  auto dot = [](const double a[3], const double b[3]) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; };
+  for (int i = 0; i < 16; ++i) if (!std::isfinite(q[i])) return;
+  const double pl = norm(pn);
+  if (!(pl > 1e-30)) return;
+  double nl[3];
+  for (int i = 0; i < 3; ++i) { nl[i] = norm(n[i]); if (!(nl[i] > 1e-30)) return; }
+  // x with pn.x = a0, n_i.x = a1, n_j.x = a2 (Cramer); false if the three planes are near-dependent
+  auto solve = [&](int i, int j, double a0, double a1, double a2, double x[3]) {
+    const double *r0 = pn, *r1 = n[i], *r2 = n[j];
+    const double c0[3] = {r1[1] * r2[2] - r1[2] * r2[1], r1[2] * r2[0] - r1[0] * r2[2], r1[0] * r2[1] - r1[1] * r2[0]};
+    const double c1[3] = {r2[1] * r0[2] - r2[2] * r0[1], r2[2] * r0[0] - r2[0] * r0[2], r2[0] * r0[1] - r2[1] * r0[0]};
+    const double c2[3] = {r0[1] * r1[2] - r0[2] * r1[1], r0[2] * r1[0] - r0[0] * r1[2], r0[0] * r1[1] - r0[1] * r1[0]};
+    const double det = dot(r0, c0);
+    if (!(std::fabs(det) > 1e-9 * pl * nl[i] * nl[j])) return false;
+    for (int a = 0; a < 3; ++a) x[a] = (a0 * c0[a] + a1 * c1[a] + a2 * c2[a]) / det;
+    return std::isfinite(x[0]) && std::isfinite(x[1]) && std::isfinite(x[2]);
+  };
+  const int pi[3] = {0, 1, 2}, pj[3] = {1, 2, 0}, pm[3] = {2, 0, 1};
+  double V[3][3], pmax = 0.0;
+  for (int e = 0; e < 3; ++e) {
+    if (!solve(pi[e], pj[e], kp, k[pi[e]], k[pj[e]], V[e])) return;
+    pmax = std::fmax(pmax, norm(V[e]));
+  }
+  // bounded triangle <=> every vertex satisfies the third half-plane
+  for (int e = 0; e < 3; ++e) {
+    const int m = pm[e];
+    if (!(dot(n[m], V[e]) - k[m] >= -1e-6 * (nl[m] * pmax + std::fabs(k[m]) + 1.0))) return;
+  }
+  // push every edge plane outwards by the test's epsilon plus a bound on its fp32 evaluation error
+  const double pb = 1.5 * pmax + 1.0;
+  double kd[3];
+  for (int i = 0; i < 3; ++i) kd[i] = k[i] - (1e-6 + 2e-6 * (nl[i] * pb + std::fabs(k[i])));
+  double W[3][3], c[3] = {0, 0, 0};
+  for (int e = 0; e < 3; ++e) {
+    if (!solve(pi[e], pj[e], kp, kd[pi[e]], kd[pj[e]], W[e])) return;
+    for (int a = 0; a < 3; ++a) c[a] += W[e][a] / 3.0;
+  }
+  double rad = 0.0;
+  for (int e = 0; e < 3; ++e) {
+    const double d[3] = {W[e][0] - c[0], W[e][1] - c[1], W[e][2] - c[2]};
+    rad = std::fmax(rad, norm(d));
+  }
+  // hit points are float-rounded and only approximately on the plane
+  rad = (rad + 1e-5 * (pb + std::fabs(kp) / pl) + 1e-6 * norm(c)) * 1.0001;
+  if (!std::isfinite(rad) || !(rad < 1e30)) return;
+  out[0] = (float)c[0]; out[1] = (float)c[1]; out[2] = (float)c[2];
+  out[3] = std::nextafter((float)rad, INFINITY);
+}
 
 int mrt_scene_upload(mrt_ctx *ctx, const mrt_scene_desc *s)
 {
@@ -156,7 +235,7 @@ int mrt_scene_upload(mrt_ctx *ctx, const mrt_scene_desc *s)
   size_t off = 0;
   auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
   const size_t o_cx = take(ns * 4), o_cy = take(ns * 4), o_cz = take(ns * 4), o_r = take(ns * 4), o_so = take(ns * 4);
-  const size_t o_tri = take(nt * 16 * 4), o_to = take(nt * 4);
+  const size_t o_tri = take(nt * 16 * 4), o_to = take(nt * 4), o_tb = take(nt * 4 * 4);
   const size_t o_mk = take(no), o_mrgb = take(no * 12);
   const size_t o_lk = take(nl), o_lv = take(nl * 12), o_lc = take(nl * 12);
   const size_t total = off ? off : 256;
@@ -167,6 +246,12 @@ int mrt_scene_upload(mrt_ctx *ctx, const mrt_scene_desc *s)
   put(o_cx, s->sphere_cx, ns * 4); put(o_cy, s->sphere_cy, ns * 4); put(o_cz, s->sphere_cz, ns * 4);
   put(o_r, s->sphere_r, ns * 4);   put(o_so, s->sphere_obj, ns * 4);
   put(o_tri, s->tri, nt * 64);     put(o_to, s->tri_obj, nt * 4);
+  for (size_t i = 0; i < nt; ++i) {
+    float q[16], b[4];
+    for (int k = 0; k < 16; ++k) q[k] = s->tri[k * nt + i];
+    tri_bound(q, b);
+    for (int k = 0; k < 4; ++k) ((float *)(img.data() + o_tb))[k * nt + i] = b[k];
+  }
   put(o_mk, s->mat_kind, no);      put(o_mrgb, s->mat_rgb, no * 12);
   put(o_lk, s->light_kind, nl);    put(o_lv, s->light_vec, nl * 12); put(o_lc, s->light_rgb, nl * 12);
 
@@ -185,6 +270,7 @@ int mrt_scene_upload(mrt_ctx *ctx, const mrt_scene_desc *s)
   d.sph_cx = (const float *)(b + o_cx); d.sph_cy = (const float *)(b + o_cy); d.sph_cz = (const float *)(b + o_cz);
   d.sph_r = (const float *)(b + o_r);   d.sph_obj = (const int32_t *)(b + o_so); d.ns = (int32_t)ns;
   d.tri = (const float *)(b + o_tri);   d.tri_obj = (const int32_t *)(b + o_to); d.nt = (int32_t)nt;
+  d.tri_bx = (const float *)(b + o_tb); d.tri_by = d.tri_bx + nt; d.tri_bz = d.tri_bx + 2 * nt; d.tri_br = d.tri_bx + 3 * nt;
   d.mat_kind = b + o_mk; d.mat_rgb = (const float *)(b + o_mrgb); d.nobj = (int32_t)no;
   d.light_kind = b + o_lk; d.light_vec = (const float *)(b + o_lv); d.light_rgb = (const float *)(b + o_lc);
   d.nl = (int32_t)nl;
@@ -249,7 +335,7 @@ int mrt_render_device(mrt_ctx *ctx, const mrt_camera *cam, const mrt_render_para
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   hipStream_t st = (hipStream_t)stream; // NULL = HIP's default stream, as everywhere in HIP
   if (A.stats) HIP_TRY(ctx, hipMemsetAsync(A.stats, 0, 4 * sizeof(unsigned long long), st));
-  HIP_TRY(ctx, mrt::launch_render(A, st));
+  HIP_TRY(ctx, ctx->cull ? mrt::launch_render_cull(A, st) : mrt::launch_render(A, st));
   return MRT_OK;
 }
 
@@ -275,7 +361,7 @@ int mrt_render(mrt_ctx *ctx, const mrt_camera *cam, const mrt_render_params *par
   A.stats = stats ? ctx->stats_dev : nullptr;
   if (A.stats) HIP_TRY(ctx, hipMemsetAsync(A.stats, 0, 4 * sizeof(unsigned long long), ctx->stream));
   HIP_TRY(ctx, hipEventRecord(ctx->ev0, ctx->stream));
-  HIP_TRY(ctx, mrt::launch_render(A, ctx->stream));
+  HIP_TRY(ctx, ctx->cull ? mrt::launch_render_cull(A, ctx->stream) : mrt::launch_render(A, ctx->stream));
   HIP_TRY(ctx, hipEventRecord(ctx->ev1, ctx->stream));
   if (npix) {
     HIP_TRY(ctx, hipMemcpyAsync(rgb, A.rgb, npix * 12, hipMemcpyDeviceToHost, ctx->stream));

@@ -1,0 +1,439 @@
+// mrt_cull.hip -- the default render kernel: per-tile conservative culling in front of the exact tests.
+//
+// The reference tests every ray against every object (src/main.cu:67-77, core/light.cuh:153-158).  The
+// results of that loop depend only on the primitives a ray can actually hit, so this kernel first asks,
+// once per 8x8 pixel tile (one wave64), which primitives can be hit by ANY ray of the tile:
+//
+//   * the 64 lanes each take a DIFFERENT primitive (coalesced SoA loads: 64 primitives per instruction)
+//     and test its bounding sphere against a bound of the tile's ray bundle
+//       - primary rays:   a circular cone from the camera origin around the tile's four corner rays
+//       - shadow rays:    the swept sphere of the tile's hit points along the light direction
+//                         (directional light) or towards the light position (point light);
+//   * __ballot turns the 64 verdicts into a wave-uniform mask; the wave walks the set bits in ascending
+//     primitive order and runs the EXACT reference test (same fp32 operations, same order as
+//     mrt_kernels.hip and the oracle) for all 64 pixels against that primitive, whose record is
+//     broadcast from the culling lane's registers (v_readlane) or fetched with scalar loads.
+//
+// Culling never changes a result, only the number of exact tests: every bound is inflated by far more
+// than the fp32 rounding of the exact test can move a verdict (see the margins below), a NaN or an
+// infinite bound always passes, and tests/test_gpu_parity.py checks the buffers bit for bit against the
+// brute-force kernel (MRT_CULL=0) and the oracle.  There is no LDS and no barrier in this kernel: every
+// wave is independent.
+
+#include "mrt_internal.h"
+#include "mrt_device.h"
+
+#include <cstdlib>
+
+namespace mrt {
+
+// ---- margins ----------------------------------------------------------------------------------------
+// Exact sphere test: disc = b*b - a*c >= 0 in fp32.  With L = |o - c| the rounding error of disc is below
+// 10 eps a L^2 = 6e-7 a L^2, so disc >= 0 implies (true distance ray-centre)^2 <= r^2 + 6e-7 L^2.
+// The cull radius uses 4e-6 L^2 (6x that), then 0.1 % and 1e-6 on top for the cull arithmetic itself.
+#define CULL_DISC_SLACK 4e-6f
+#define CULL_REL 1.001f
+#define CULL_ABS 1e-6f
+// cancellation in |w|^2 - proj^2: lower bound of the perpendicular distance
+#define CULL_PERP_SLACK 2e-6f
+
+__device__ __forceinline__ float wave_max(float x)
+{
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) x = fmaxf(x, __shfl_xor(x, off, 64));
+  return x;
+}
+__device__ __forceinline__ float wave_min(float x)
+{
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) x = fminf(x, __shfl_xor(x, off, 64));
+  return x;
+}
+__device__ __forceinline__ float bcast(float x, int lane)
+{
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), lane));
+}
+
+// effective radius of a sphere of squared radius rr seen from distance <= Lmax
+__device__ __forceinline__ float sphere_cull_radius(float rr, float Lmax2)
+{
+  return sqrtf(rr + CULL_DISC_SLACK * Lmax2) * CULL_REL + CULL_ABS;
+}
+
+// Cone {x : angle(x - apex, axis) <= theta}: true when the ball (w = centre - apex, radius reff) may
+// touch it.  dist(ball centre, cone) >= perp*cos - proj*sin (distance to the supporting half-space).
+__device__ __forceinline__ bool ball_may_touch_cone(float wx, float wy, float wz, float reff, float ax, float ay,
+                                                    float az, float cosT, float sinT)
+{
+  const float L2 = dot3(wx, wy, wz, wx, wy, wz);
+  const float proj = dot3(wx, wy, wz, ax, ay, az);
+  const float perp = sqrtf(fmaxf(L2 - proj * proj - CULL_PERP_SLACK * L2, 0.0f));
+  return !(perp * cosT - proj * sinT > reff);
+}
+
+// Ray bundle {m + e + t*D : |e| <= rho, t >= 0} (directional light), D ~ unit: true when the ball may touch it
+__device__ __forceinline__ bool ball_may_touch_sweep(float wx, float wy, float wz, float reach, float Dx, float Dy,
+                                                     float Dz, float DD)
+{
+  const float L2 = dot3(wx, wy, wz, wx, wy, wz);
+  const float proj = dot3(wx, wy, wz, Dx, Dy, Dz);
+  // squared distance to the half-line; behind the origin the distance is |w|
+  const float d2 = (proj > 0.0f) ? (L2 - (proj * proj) / DD) : L2;
+  const float dist = sqrtf(fmaxf(d2 - CULL_PERP_SLACK * L2, 0.0f));
+  return !(dist > reach);
+}
+
+// Segment bundle: every shadow ray of the tile runs from a point within rho of m to the light position
+// m + e (point light), so it stays within rho of the segment [m, m+e].
+__device__ __forceinline__ bool ball_may_touch_segment(float wx, float wy, float wz, float reach, float ex, float ey,
+                                                       float ez, float ee)
+{
+  const float L2 = dot3(wx, wy, wz, wx, wy, wz);
+  float s = dot3(wx, wy, wz, ex, ey, ez) / ee; // ee == 0 gives NaN/inf: clamped below, NaN -> pass
+  s = fminf(fmaxf(s, 0.0f), 1.0f);
+  const float qx = wx - s * ex, qy = wy - s * ey, qz = wz - s * ez;
+  const float d2 = dot3(qx, qy, qz, qx, qy, qz);
+  const float dist = sqrtf(fmaxf(d2 - CULL_PERP_SLACK * (L2 + ee), 0.0f));
+  return !(dist > reach);
+}
+
+struct Light {
+  int kind;
+  float vx, vy, vz;
+};
+
+// Shadow-ray bundle of one light over one tile, and the per-lane ray.
+struct Bundle {
+  // tile-uniform
+  float mx, my, mz, rho;   // hit points of the tile lie within rho of m
+  float Dx, Dy, Dz, DD;    // directional: ray direction and D.D;  point: e = pos - m and e.e
+  bool point;
+};
+
+// Does the ball (centre c, squared radius rr for spheres / radius rb for triangle bounds) possibly touch
+// one of the tile's shadow rays?
+__device__ __forceinline__ bool bundle_may_touch(const Bundle &B, float cx, float cy, float cz, float reff)
+{
+  const float wx = cx - B.mx, wy = cy - B.my, wz = cz - B.mz;
+  const float reach = (reff + B.rho) * CULL_REL + CULL_ABS;
+  return B.point ? ball_may_touch_segment(wx, wy, wz, reach, B.Dx, B.Dy, B.Dz, B.DD)
+                 : ball_may_touch_sweep(wx, wy, wz, reach, B.Dx, B.Dy, B.Dz, B.DD);
+}
+
+__global__ __launch_bounds__(256) void render_cull_kernel(RenderArgs A)
+{
+  const DevScene &sc = A.sc;
+  const DevCamera &cam = A.cam;
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int tx = lane & 7, ty = lane >> 3;
+  const int ns = sc.ns, nt = sc.nt;
+
+  const int tiles_x = (A.W + 7) / 8;
+  const int ntiles = tiles_x * ((A.local_rows + 7) / 8);
+  const int tile = blockIdx.x * 4 + wave;
+  if (tile >= ntiles) return; // waves are independent: no barrier anywhere below
+  const int tile_y = tile / tiles_x, tile_x = tile - tile_y * tiles_x;
+  const int col = tile_x * 8 + tx;
+  const int lrow = tile_y * 8 + ty;
+  // strips are multiples of 8 rows, so a tile never straddles two strips
+  const int lrow0 = tile_y * 8;
+  const int strip = lrow0 / A.strip_rows;
+  const int grow0 = (strip * A.nranks + A.rank) * A.strip_rows + (lrow0 - strip * A.strip_rows);
+  const int grow = grow0 + ty;
+  const bool valid = (lrow < A.local_rows) && (grow < A.H) && (col < A.W);
+
+  // ---- cone around the tile's rays.  Corners one pixel outside the tile, which also covers the
+  //      sub-pixel offsets of the 121-spp pattern (within (-11/13, +9/13) pixel) ----
+  float cax, cay, caz, cosT = 2.0f, sinT;
+  {
+    const float ulo = float(tile_x * 8 - 1) / float(A.W), uhi = float(tile_x * 8 + 8) / float(A.W);
+    const float vlo = float(grow0 - 1) / float(A.H), vhi = float(grow0 + 8) / float(A.H);
+    const float um = 0.5f * (ulo + uhi), vm = 0.5f * (vlo + vhi);
+    cax = ((cam.ux + um * cam.hx) + vm * cam.vx) - cam.ox;
+    cay = ((cam.uy + um * cam.hy) + vm * cam.vy) - cam.oy;
+    caz = ((cam.uz + um * cam.hz) + vm * cam.vz) - cam.oz;
+    normalize3(cax, cay, caz);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float su = (k & 1) ? uhi : ulo, sv = (k & 2) ? vhi : vlo;
+      float x = ((cam.ux + su * cam.hx) + sv * cam.vx) - cam.ox;
+      float y = ((cam.uy + su * cam.hy) + sv * cam.vy) - cam.oy;
+      float z = ((cam.uz + su * cam.hz) + sv * cam.vz) - cam.oz;
+      normalize3(x, y, z);
+      cosT = fminf(cosT, dot3(cax, cay, caz, x, y, z));
+    }
+    cosT = cosT * (1.0f - 1e-5f) - 1e-6f;
+    // a cone of 90 degrees or more (or a NaN camera) cannot cull: cos = -1 makes every ball pass
+    if (!(cosT > 0.0f)) cosT = -1.0f;
+    sinT = sqrtf(fmaxf(1.0f - cosT * cosT, 0.0f)) * (1.0f + 1e-5f) + 1e-6f;
+    if (cosT < 0.0f) sinT = 0.0f;
+  }
+
+  float accr = 0.0f, accg = 0.0f, accb = 0.0f;
+  int out_id = -1;
+  float out_t = MRT_INF;
+  unsigned int n_shadow = 0, n_hit = 0, n_occl = 0;
+  const int nsamp = A.spp;
+  const float DIVW = 13.0f, DIVH = 13.0f;
+  const float v = float(grow) / float(A.H); // src/main.cu:137
+
+  for (int sidx = 0; sidx < nsamp; ++sidx) {
+    float offx = 0.0f, offy = 0.0f;
+    if (nsamp > 1) { // pipeline/multisample_mesh.cuh:23-30
+      int r = sidx / 11, c = sidx - r * 11;
+      offy = (-1.0f + 2.0f * float(r + 1) / DIVH) / float(A.H);
+      offx = (-1.0f + 2.0f * float(c + 1) / DIVW) / float(A.W);
+    }
+    // ---- primary ray: pipeline/viewport.cuh:30-34 ----
+    float su = float(col) / float(A.W), sv = v; // src/main.cu:136
+    if (nsamp > 1) { su = su + offx; sv = v + offy; }
+    const float dx = ((cam.ux + su * cam.hx) + sv * cam.vx) - cam.ox;
+    const float dy = ((cam.uy + su * cam.hy) + sv * cam.vy) - cam.oy;
+    const float dz = ((cam.uz + su * cam.hz) + sv * cam.vz) - cam.oz;
+    const float aa = dot3(dx, dy, dz, dx, dy, dz);
+    float best_t = MRT_INF;
+    int best_obj = 0x7fffffff, best_prim = -1;
+
+    // ---- closest hit over spheres: src/main.cu:60-77, core/sphere.cuh:32-73, interval [0.01, inf] ----
+    for (int base = 0; base < ns; base += 64) {
+      const int i = base + lane;
+      float cx = 0.0f, cy = 0.0f, cz = 0.0f, r = 0.0f;
+      bool pass = false;
+      if (i < ns) {
+        cx = sc.sph_cx[i]; cy = sc.sph_cy[i]; cz = sc.sph_cz[i]; r = sc.sph_r[i];
+        const float wx = cx - cam.ox, wy = cy - cam.oy, wz = cz - cam.oz;
+        const float L2 = dot3(wx, wy, wz, wx, wy, wz);
+        pass = ball_may_touch_cone(wx, wy, wz, sphere_cull_radius(r * r, L2), cax, cay, caz, cosT, sinT);
+      }
+      unsigned long long mask = __ballot(pass);
+      while (mask) {
+        const int j = __builtin_ctzll(mask);
+        mask &= mask - 1;
+        const float scx = bcast(cx, j), scy = bcast(cy, j), scz = bcast(cz, j), sr = bcast(r, j);
+        const float ocx = cam.ox - scx, ocy = cam.oy - scy, ocz = cam.oz - scz;
+        const float b = dot3(ocx, ocy, ocz, dx, dy, dz);
+        const float c = dot3(ocx, ocy, ocz, ocx, ocy, ocz) - sr * sr;
+        const float disc = b * b - aa * c;
+        if (disc >= 0.0f) {
+          float t;
+          if (sphere_roots(aa, b, disc, 0.01f, MRT_INF, t)) {
+            const int obj = sc.sph_obj[base + j];
+            if (t < best_t || (t == best_t && t < MRT_INF && obj < best_obj)) {
+              best_t = t; best_obj = obj; best_prim = base + j;
+            }
+          }
+        }
+      }
+    }
+
+    // ---- closest hit over triangles: core/triangle.cuh:77-103 ----
+    for (int base = 0; base < nt; base += 64) {
+      const int i = base + lane;
+      bool pass = false;
+      if (i < nt) {
+        const float wx = sc.tri_bx[i] - cam.ox, wy = sc.tri_by[i] - cam.oy, wz = sc.tri_bz[i] - cam.oz;
+        pass = ball_may_touch_cone(wx, wy, wz, sc.tri_br[i] * CULL_REL + CULL_ABS, cax, cay, caz, cosT, sinT);
+      }
+      unsigned long long mask = __ballot(pass);
+      while (mask) {
+        const int j = __builtin_ctzll(mask);
+        mask &= mask - 1;
+        const float *q = sc.tri + (base + j); // wave-uniform address: scalar loads
+        const float pnx = q[0], pny = q[nt], pnz = q[2 * nt], kp = q[3 * nt];
+        const float rdn = dot3(dx, dy, dz, pnx, pny, pnz);
+        const float t = (kp - dot3(cam.ox, cam.oy, cam.oz, pnx, pny, pnz)) / rdn;
+        const float px = cam.ox + t * dx, py = cam.oy + t * dy, pz = cam.oz + t * dz;
+        const float e0 = dot3(q[4 * nt], q[5 * nt], q[6 * nt], px, py, pz) - q[7 * nt];
+        const float e1 = dot3(q[8 * nt], q[9 * nt], q[10 * nt], px, py, pz) - q[11 * nt];
+        const float e2 = dot3(q[12 * nt], q[13 * nt], q[14 * nt], px, py, pz) - q[15 * nt];
+        const bool hit = (rdn != 0.0f) & (e0 > -1e-6f) & (e1 > -1e-6f) & (e2 > -1e-6f) & (0.01f <= t) & (t <= MRT_INF);
+        if (hit) {
+          const int obj = sc.tri_obj[base + j];
+          if (t < best_t || (t == best_t && t < MRT_INF && obj < best_obj)) {
+            best_t = t; best_obj = obj; best_prim = ns + base + j;
+          }
+        }
+      }
+    }
+
+    // ---- hit record of the winner (core/sphere.cuh:45-47, core/triangle.cuh:96-97) ----
+    const bool have_hit = best_prim >= 0;
+    float hpx = 0.0f, hpy = 0.0f, hpz = 0.0f, hnx = 0.0f, hny = 0.0f, hnz = 0.0f;
+    if (have_hit) {
+      hpx = cam.ox + best_t * dx; hpy = cam.oy + best_t * dy; hpz = cam.oz + best_t * dz;
+      if (best_prim < ns) {
+        float nx = hpx - sc.sph_cx[best_prim], ny = hpy - sc.sph_cy[best_prim], nz = hpz - sc.sph_cz[best_prim];
+        normalize3(nx, ny, nz);
+        hnx = nx; hny = ny; hnz = nz;
+      } else {
+        const float *q = sc.tri + (best_prim - ns);
+        const float pnx = q[0], pny = q[nt], pnz = q[2 * nt];
+        const bool front = dot3(dx, dy, dz, pnx, pny, pnz) < 0;
+        hnx = front ? pnx : -pnx; hny = front ? pny : -pny; hnz = front ? pnz : -pnz;
+      }
+      if (valid) n_hit++;
+    }
+
+    // ---- shadow rays + direct light: core/light.cuh:135-178 ----
+    float lr = 0.0f, lg = 0.0f, lb = 0.0f;
+    bool have_light = false;
+    if (__any(have_hit)) {
+      // ball around the tile's hit points (any subset of them is covered too)
+      Bundle B;
+      {
+        const float big = 3.0e38f;
+        const float lox = wave_min(have_hit ? hpx : big), hix = wave_max(have_hit ? hpx : -big);
+        const float loy = wave_min(have_hit ? hpy : big), hiy = wave_max(have_hit ? hpy : -big);
+        const float loz = wave_min(have_hit ? hpz : big), hiz = wave_max(have_hit ? hpz : -big);
+        B.mx = 0.5f * (lox + hix); B.my = 0.5f * (loy + hiy); B.mz = 0.5f * (loz + hiz);
+        const float ex = hpx - B.mx, ey = hpy - B.my, ez = hpz - B.mz;
+        const float e2 = have_hit ? dot3(ex, ey, ez, ex, ey, ez) : 0.0f;
+        B.rho = sqrtf(wave_max(e2)) * CULL_REL + CULL_ABS; // a NaN hit point makes every test below pass
+      }
+      for (int li = 0; li < sc.nl; ++li) {
+        const int lkind = sc.light_kind[li];
+        const float lvx = sc.light_vec[3 * li], lvy = sc.light_vec[3 * li + 1], lvz = sc.light_vec[3 * li + 2];
+        // per-lane shadow ray and the light's "hit record" (ray_from: core/light.cuh:73-81 / :47-53)
+        float sdx, sdy, sdz, tl, lnx, lny, lnz;
+        if (lkind == 0) {
+          sdx = -lvx; sdy = -lvy; sdz = -lvz; tl = MRT_INF;
+          lnx = lvx; lny = lvy; lnz = lvz;
+          B.point = false;
+          B.Dx = sdx; B.Dy = sdy; B.Dz = sdz;
+        } else {
+          sdx = lvx - hpx; sdy = lvy - hpy; sdz = lvz - hpz; tl = 1.0f;
+          lnx = hpx - lvx; lny = hpy - lvy; lnz = hpz - lvz;
+          normalize3(lnx, lny, lnz);
+          B.point = true;
+          B.Dx = lvx - B.mx; B.Dy = lvy - B.my; B.Dz = lvz - B.mz;
+        }
+        B.DD = dot3(B.Dx, B.Dy, B.Dz, B.Dx, B.Dy, B.Dz);
+        const float sa = dot3(sdx, sdy, sdz, sdx, sdy, sdz);
+        // the light must not shine through the surface, core/light.cuh:148
+        const bool need = have_hit && !(dot3(sdx, sdy, sdz, hnx, hny, hnz) < 0);
+        bool open = need;
+        bool wave_open = __any(open);
+
+        // any-hit over spheres, interval [1e-3, t_light] (core/light.cuh:28-33)
+        for (int base = 0; base < ns && wave_open; base += 64) {
+          const int i = base + lane;
+          float cx = 0.0f, cy = 0.0f, cz = 0.0f, r = 0.0f;
+          bool pass = false;
+          if (i < ns) {
+            cx = sc.sph_cx[i]; cy = sc.sph_cy[i]; cz = sc.sph_cz[i]; r = sc.sph_r[i];
+            const float wx = cx - B.mx, wy = cy - B.my, wz = cz - B.mz;
+            const float Lm = sqrtf(dot3(wx, wy, wz, wx, wy, wz)) + B.rho; // >= |hit point - centre| in the tile
+            pass = bundle_may_touch(B, cx, cy, cz, sphere_cull_radius(r * r, Lm * Lm));
+          }
+          unsigned long long mask = __ballot(pass);
+          while (mask) {
+            const int j = __builtin_ctzll(mask);
+            mask &= mask - 1;
+            const float scx = bcast(cx, j), scy = bcast(cy, j), scz = bcast(cz, j), sr = bcast(r, j);
+            const float ocx = hpx - scx, ocy = hpy - scy, ocz = hpz - scz;
+            const float b = dot3(ocx, ocy, ocz, sdx, sdy, sdz);
+            const float c = dot3(ocx, ocy, ocz, ocx, ocy, ocz) - sr * sr;
+            const float disc = b * b - sa * c;
+            if (open && disc >= 0.0f) {
+              float t;
+              if (sphere_roots(sa, b, disc, 1e-3f, tl, t)) open = false;
+            }
+            if (!__any(open)) { wave_open = false; break; } // ballot early-out
+          }
+        }
+        // any-hit over triangles
+        for (int base = 0; base < nt && wave_open; base += 64) {
+          const int i = base + lane;
+          bool pass = false;
+          if (i < nt) pass = bundle_may_touch(B, sc.tri_bx[i], sc.tri_by[i], sc.tri_bz[i], sc.tri_br[i]);
+          unsigned long long mask = __ballot(pass);
+          while (mask) {
+            const int j = __builtin_ctzll(mask);
+            mask &= mask - 1;
+            const float *q = sc.tri + (base + j);
+            const float pnx = q[0], pny = q[nt], pnz = q[2 * nt], kp = q[3 * nt];
+            const float rdn = dot3(sdx, sdy, sdz, pnx, pny, pnz);
+            const float t = (kp - dot3(hpx, hpy, hpz, pnx, pny, pnz)) / rdn;
+            const float px = hpx + t * sdx, py = hpy + t * sdy, pz = hpz + t * sdz;
+            const float e0 = dot3(q[4 * nt], q[5 * nt], q[6 * nt], px, py, pz) - q[7 * nt];
+            const float e1 = dot3(q[8 * nt], q[9 * nt], q[10 * nt], px, py, pz) - q[11 * nt];
+            const float e2 = dot3(q[12 * nt], q[13 * nt], q[14 * nt], px, py, pz) - q[15 * nt];
+            const bool h = (rdn != 0.0f) & (e0 > -1e-6f) & (e1 > -1e-6f) & (e2 > -1e-6f) & (1e-3f <= t) & (t <= tl);
+            if (open && h) open = false;
+            if (!__any(open)) { wave_open = false; break; }
+          }
+        }
+
+        if (need && valid) { n_shadow++; if (!open) n_occl++; }
+        if (open) {
+          // light_bounce with the LIGHT's normal, as the reference passes it (core/light.cuh:164-168)
+          const float lcr = sc.light_rgb[3 * li], lcg = sc.light_rgb[3 * li + 1], lcb = sc.light_rgb[3 * li + 2];
+          const float dn = dot3(sdx, sdy, sdz, lnx, lny, lnz);
+          float cr, cg, cb;
+          if (sc.mat_kind[best_obj] == 0) { // DiffuseMaterial::light_bounce, core/material.cuh:63-75
+            const float scale = -dn;
+            if (scale > 0.0f) { cr = scale * lcr; cg = scale * lcg; cb = scale * lcb; }
+            else { cr = 0.0f; cg = 0.0f; cb = 0.0f; }
+          } else {                          // MetallicMaterial::light_bounce, core/material.cuh:134-158
+            const float s2 = 2.0f * dn;
+            const float rx = sdx - s2 * lnx, ry = sdy - s2 * lny, rz = sdz - s2 * lnz;
+            if (dot3(rx, ry, rz, dx, dy, dz) < -0.99f) { cr = lcr; cg = lcg; cb = lcb; }
+            else { cr = 0.001f; cg = 0.001f; cb = 0.001f; }
+          }
+          if (have_light) { lr += cr; lg += cg; lb += cb; }
+          else { lr = cr; lg = cg; lb = cb; have_light = true; }
+        }
+      }
+    }
+
+    // ---- combine: src/main.cu:91-104 with MAX_RECURSION_DEPTH = 0 ----
+    float cr, cg, cb;
+    if (have_hit) {
+      const float *m = sc.mat_rgb + 3 * best_obj;
+      const float mr = m[0], mg = m[1], mb = m[2];
+      const float inc = 0.01f; // what the depth-1 call returns, src/main.cu:51-53
+      if (have_light) { cr = inc * mr + lr * mr; cg = inc * mg + lg * mg; cb = inc * mb + lb * mb; }
+      else { cr = inc * mr; cg = inc * mg; cb = inc * mb; }
+    } else {
+      float nx = dx, ny = dy, nz = dz;
+      normalize3(nx, ny, nz);
+      const float y = 0.5f * (ny + 1.0f);
+      const float w0 = 1.0f - y;
+      cr = w0 * 1.0f + y * 0.5f; cg = w0 * 1.0f + y * 0.7f; cb = w0 * 1.0f + y * 1.0f;
+    }
+    accr += cr; accg += cg; accb += cb; // src/main.cu:151
+    out_id = have_hit ? best_obj : -1;
+    out_t = best_t;
+  }
+
+  if (valid) { // src/main.cu:155
+    const float fn = float(nsamp);
+    const size_t pix = size_t(lrow) * A.W + col;
+    A.rgb[3 * pix + 0] = accr / fn;
+    A.rgb[3 * pix + 1] = accg / fn;
+    A.rgb[3 * pix + 2] = accb / fn;
+    if (A.id) A.id[pix] = out_id;
+    if (A.t) A.t[pix] = out_t;
+  }
+
+  if (A.stats) {
+    unsigned int v4[4] = {(valid ? 1u : 0u) * (unsigned)nsamp, n_shadow, n_hit, n_occl};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      unsigned int x = v4[k];
+      for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, 64);
+      if (lane == 0 && x) atomicAdd(&A.stats[k], (unsigned long long)x);
+    }
+  }
+}
+
+hipError_t launch_render_cull(const RenderArgs &A, hipStream_t stream)
+{
+  const int ntiles = ((A.W + 7) / 8) * ((A.local_rows + 7) / 8);
+  if (ntiles == 0) return hipSuccess;
+  hipLaunchKernelGGL(render_cull_kernel, dim3((ntiles + 3) / 4), dim3(256), 0, stream, A);
+  return hipGetLastError();
+}
+
+} // namespace mrt

@@ -15,6 +15,9 @@ struct DevScene {
   // triangles: 16 streams of nt floats, stream s at tri + s*nt (core/triangle.cuh:118-122)
   const float *tri;
   const int32_t *tri_obj;
+  // conservative bounding spheres of the regions the triangle hit test accepts (built at upload,
+  // mrt_api.cpp tri_bound); radius +inf = never culled.  4 streams of nt floats.
+  const float *tri_bx, *tri_by, *tri_bz, *tri_br;
   int32_t nt;
   // per object material (core/material.cuh:78,160)
   const uint8_t *mat_kind;
@@ -49,6 +52,8 @@ struct RenderArgs {
   int32_t resident;                 // whole scene staged once
   int32_t s_cap, t_cap;             // primitives per LDS chunk
 };
+
+hipError_t launch_render_cull(const RenderArgs &args, hipStream_t stream);
 
 // launchers (mrt_kernels.hip)
 hipError_t launch_render(const RenderArgs &args, hipStream_t stream);

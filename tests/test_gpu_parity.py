@@ -19,6 +19,15 @@ GOLD = os.path.join(os.path.dirname(__file__), "golden")
 RGB_TOL = 1.0 / 255.0
 
 
+@pytest.fixture(params=["cull", "brute"], autouse=True)
+def kernel_mode(request, gpu_ctx):
+    """Every test runs against both render kernels: the tile-culling one (default) and the brute-force
+    one that walks every primitive for every ray like the reference loops."""
+    gpu_ctx.set_cull(request.param == "cull")
+    yield request.param
+    gpu_ctx.set_cull(True)
+
+
 def _load(name):
     with open(os.path.join(GOLD, name)) as f:
         return json.load(f)
@@ -288,6 +297,81 @@ def test_multisample_121_mode(gpu_ctx):
     r = O.Scene.default().render(cam, 128, 64, spp=121, nthreads=8)
     assert_frame_parity(g, r, "121 spp")
     assert g["stats"]["primary_rays"] == 128 * 64 * 121
+    assert_stats_parity(g["stats"], r["stats"])
+
+
+# ------------------------------------------------------------------ culling never changes a result
+
+def _render_both(ctx, cam, W, H, **kw):
+    ctx.set_cull(True)
+    a = ctx.render(cam, W, H, **kw)
+    ctx.set_cull(False)
+    b = ctx.render(cam, W, H, **kw)
+    ctx.set_cull(True)
+    return a, b
+
+
+def _assert_same(a, b, what):
+    for k in ("id", "t", "rgb"):
+        assert np.array_equal(a[k], b[k], equal_nan=True), f"{what}: {k} differs between culling and brute force"
+    for k in ("primary_rays", "shadow_rays", "hit_pixels", "occluded"):
+        assert a["stats"][k] == b["stats"][k], f"{what}: {k}"
+
+
+@pytest.mark.parametrize("name", ["C3_spheres_4k", "C5_lights_1080p", "terrain_40k_1080p"])
+def test_culling_matches_brute_force_at_full_size(gpu_ctx, kernel_mode, name):
+    """Size-independent property at BASELINE.json's full frame sizes, where the oracle is too slow:
+    the culled kernel and the every-ray-every-primitive kernel must agree bit for bit."""
+    if kernel_mode != "cull":
+        pytest.skip("compares both kernels itself")
+    if name == "C3_spheres_4k":
+        spec, (W, H) = scenes.sphere_field(10000), (3840, 2160)
+    elif name == "C5_lights_1080p":
+        spec, (W, H) = scenes.light_stress(), (1920, 1080)
+    else:
+        spec, (W, H) = scenes.triangle_terrain(200, 100), (1920, 1080)
+    gpu_ctx.upload(spec.flatten())
+    a, b = _render_both(gpu_ctx, spec.cam12(W / H), W, H)
+    _assert_same(a, b, name)
+    assert a["stats"]["hit_pixels"] > 10000
+
+
+def _random_scene(seed):
+    """Adversarial mix for the culling bounds: radii over 5 decades, spheres around and behind the
+    camera, slivers, triangles whose plane passes through the world origin (degenerate edge planes:
+    infinite bound), lights of both kinds, one of them inside the geometry."""
+    rng = np.random.default_rng(seed)
+    ns, nt = int(rng.integers(1, 90)), int(rng.integers(1, 90))
+    c = rng.uniform(-30, 30, (ns, 3))
+    r = 10.0 ** rng.uniform(-3, 1.5, ns)
+    sp = np.concatenate([c, r[:, None]], axis=1).astype(np.float32)
+    a = rng.uniform(-30, 30, (nt, 3))
+    size = 10.0 ** rng.uniform(-2, 1.3, (nt, 1))
+    tv = np.stack([a, a + rng.normal(size=(nt, 3)) * size, a + rng.normal(size=(nt, 3)) * size], axis=1)
+    tv[::7, 0] = 0.0                                   # a vertex at the world origin -> plane through origin
+    tv[3::11, 2] = tv[3::11, 1] + 1e-4 * rng.normal(size=tv[3::11, 1].shape)  # slivers
+    tv = tv.astype(np.float32)
+    n = ns + nt
+    order = rng.permutation(n)
+    sphere_obj, tri_obj = np.sort(order[:ns]), np.sort(order[ns:])
+    kind, rgb = scenes._cycle_materials(n)
+    lights = [(capi.LIGHT_DIRECTIONAL, tuple(rng.normal(size=3)), (3.0, 2.0, 1.0)),
+              (capi.LIGHT_POINT, tuple(rng.uniform(-25, 25, 3)), (0.5, 0.7, 0.9)),
+              (capi.LIGHT_POINT, tuple(c[0] + 0.5 * r[0]), (1.0, 1.0, 1.0))]
+    cam = {"look_from": tuple(rng.uniform(-20, 20, 3)), "look_at": tuple(rng.uniform(-5, 5, 3)), "up": (0.1, 1.0, 0.05),
+           "vfov": float(rng.uniform(15, 100))}
+    return scenes.SceneSpec(f"random{seed}", sp, sphere_obj, tv, tri_obj, kind, rgb, lights, cam)
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_random_scenes_both_kernels_vs_oracle(gpu_ctx, seed):
+    spec = _random_scene(seed)
+    gpu_ctx.upload(spec.flatten())
+    W, H = 136, 104
+    cam = spec.cam12(W / H)
+    g = gpu_ctx.render(cam, W, H)
+    r = O.Scene.from_spec(spec).render(cam, W, H, nthreads=8)
+    assert_frame_parity(g, r, spec.name)
     assert_stats_parity(g["stats"], r["stats"])
 
 
