@@ -235,7 +235,7 @@ int mrt_scene_upload(mrt_ctx *ctx, const mrt_scene_desc *s)
   size_t off = 0;
   auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
   const size_t o_cx = take(ns * 4), o_cy = take(ns * 4), o_cz = take(ns * 4), o_r = take(ns * 4), o_so = take(ns * 4);
-  const size_t o_tri = take(nt * 16 * 4), o_to = take(nt * 4), o_tb = take(nt * 4 * 4);
+  const size_t o_tri = take(nt * 16 * 4), o_to = take(nt * 4), o_tb = take(nt * 4 * 4), o_trec = take(nt * 64);
   const size_t o_mk = take(no), o_mrgb = take(no * 12);
   const size_t o_lk = take(nl), o_lv = take(nl * 12), o_lc = take(nl * 12);
   const size_t total = off ? off : 256;
@@ -251,6 +251,7 @@ int mrt_scene_upload(mrt_ctx *ctx, const mrt_scene_desc *s)
     for (int k = 0; k < 16; ++k) q[k] = s->tri[k * nt + i];
     tri_bound(q, b);
     for (int k = 0; k < 4; ++k) ((float *)(img.data() + o_tb))[k * nt + i] = b[k];
+    std::memcpy(img.data() + o_trec + 64 * i, q, 64);
   }
   put(o_mk, s->mat_kind, no);      put(o_mrgb, s->mat_rgb, no * 12);
   put(o_lk, s->light_kind, nl);    put(o_lv, s->light_vec, nl * 12); put(o_lc, s->light_rgb, nl * 12);
@@ -271,6 +272,7 @@ int mrt_scene_upload(mrt_ctx *ctx, const mrt_scene_desc *s)
   d.sph_r = (const float *)(b + o_r);   d.sph_obj = (const int32_t *)(b + o_so); d.ns = (int32_t)ns;
   d.tri = (const float *)(b + o_tri);   d.tri_obj = (const int32_t *)(b + o_to); d.nt = (int32_t)nt;
   d.tri_bx = (const float *)(b + o_tb); d.tri_by = d.tri_bx + nt; d.tri_bz = d.tri_bx + 2 * nt; d.tri_br = d.tri_bx + 3 * nt;
+  d.tri_rec = (const float *)(b + o_trec);
   d.mat_kind = b + o_mk; d.mat_rgb = (const float *)(b + o_mrgb); d.nobj = (int32_t)no;
   d.light_kind = b + o_lk; d.light_vec = (const float *)(b + o_lv); d.light_rgb = (const float *)(b + o_lc);
   d.nl = (int32_t)nl;

@@ -34,8 +34,10 @@ namespace mrt {
 #define CULL_DISC_SLACK 4e-6f
 #define CULL_REL 1.001f
 #define CULL_ABS 1e-6f
-// cancellation in |w|^2 - proj^2: lower bound of the perpendicular distance
-#define CULL_PERP_SLACK 2e-6f
+// cancellation in |w|^2 - proj^2 and the ~1e-6 relative error of the approximate (v_rsq/v_sqrt/v_rcp)
+// arithmetic the bound tests use: lower bound of the perpendicular distance.  The bound tests never
+// need exact arithmetic -- only the exact tests behind them do.
+#define CULL_PERP_SLACK 1e-5f
 
 __device__ __forceinline__ float wave_max(float x)
 {
@@ -49,6 +51,15 @@ __device__ __forceinline__ float wave_min(float x)
   for (int off = 32; off > 0; off >>= 1) x = fminf(x, __shfl_xor(x, off, 64));
   return x;
 }
+// single-instruction approximations (1 ulp), for bound tests only
+__device__ __forceinline__ float fast_sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
+__device__ __forceinline__ float fast_rsq(float x) { return __builtin_amdgcn_rsqf(x); }
+__device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ __forceinline__ void fast_normalize(float &x, float &y, float &z)
+{
+  const float s = fast_rsq(dot3(x, y, z, x, y, z));
+  x *= s; y *= s; z *= s;
+}
 __device__ __forceinline__ float bcast(float x, int lane)
 {
   return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), lane));
@@ -57,7 +68,7 @@ __device__ __forceinline__ float bcast(float x, int lane)
 // effective radius of a sphere of squared radius rr seen from distance <= Lmax
 __device__ __forceinline__ float sphere_cull_radius(float rr, float Lmax2)
 {
-  return sqrtf(rr + CULL_DISC_SLACK * Lmax2) * CULL_REL + CULL_ABS;
+  return fast_sqrt(rr + CULL_DISC_SLACK * Lmax2) * CULL_REL + CULL_ABS;
 }
 
 // Cone {x : angle(x - apex, axis) <= theta}: true when the ball (w = centre - apex, radius reff) may
@@ -67,7 +78,7 @@ __device__ __forceinline__ bool ball_may_touch_cone(float wx, float wy, float wz
 {
   const float L2 = dot3(wx, wy, wz, wx, wy, wz);
   const float proj = dot3(wx, wy, wz, ax, ay, az);
-  const float perp = sqrtf(fmaxf(L2 - proj * proj - CULL_PERP_SLACK * L2, 0.0f));
+  const float perp = fast_sqrt(fmaxf(L2 - proj * proj - CULL_PERP_SLACK * L2, 0.0f));
   return !(perp * cosT - proj * sinT > reff);
 }
 
@@ -78,8 +89,8 @@ __device__ __forceinline__ bool ball_may_touch_sweep(float wx, float wy, float w
   const float L2 = dot3(wx, wy, wz, wx, wy, wz);
   const float proj = dot3(wx, wy, wz, Dx, Dy, Dz);
   // squared distance to the half-line; behind the origin the distance is |w|
-  const float d2 = (proj > 0.0f) ? (L2 - (proj * proj) / DD) : L2;
-  const float dist = sqrtf(fmaxf(d2 - CULL_PERP_SLACK * L2, 0.0f));
+  const float d2 = (proj > 0.0f) ? (L2 - (proj * proj) * fast_rcp(DD)) : L2;
+  const float dist = fast_sqrt(fmaxf(d2 - CULL_PERP_SLACK * L2, 0.0f));
   return !(dist > reach);
 }
 
@@ -89,11 +100,11 @@ __device__ __forceinline__ bool ball_may_touch_segment(float wx, float wy, float
                                                        float ez, float ee)
 {
   const float L2 = dot3(wx, wy, wz, wx, wy, wz);
-  float s = dot3(wx, wy, wz, ex, ey, ez) / ee; // ee == 0 gives NaN/inf: clamped below, NaN -> pass
+  float s = dot3(wx, wy, wz, ex, ey, ez) * fast_rcp(ee); // ee == 0 gives NaN/inf: clamped below, NaN -> pass
   s = fminf(fmaxf(s, 0.0f), 1.0f);
   const float qx = wx - s * ex, qy = wy - s * ey, qz = wz - s * ez;
   const float d2 = dot3(qx, qy, qz, qx, qy, qz);
-  const float dist = sqrtf(fmaxf(d2 - CULL_PERP_SLACK * (L2 + ee), 0.0f));
+  const float dist = fast_sqrt(fmaxf(d2 - CULL_PERP_SLACK * (L2 + ee), 0.0f));
   return !(dist > reach);
 }
 
@@ -153,20 +164,20 @@ __global__ __launch_bounds__(256) void render_cull_kernel(RenderArgs A)
     cax = ((cam.ux + um * cam.hx) + vm * cam.vx) - cam.ox;
     cay = ((cam.uy + um * cam.hy) + vm * cam.vy) - cam.oy;
     caz = ((cam.uz + um * cam.hz) + vm * cam.vz) - cam.oz;
-    normalize3(cax, cay, caz);
+    fast_normalize(cax, cay, caz);
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       const float su = (k & 1) ? uhi : ulo, sv = (k & 2) ? vhi : vlo;
       float x = ((cam.ux + su * cam.hx) + sv * cam.vx) - cam.ox;
       float y = ((cam.uy + su * cam.hy) + sv * cam.vy) - cam.oy;
       float z = ((cam.uz + su * cam.hz) + sv * cam.vz) - cam.oz;
-      normalize3(x, y, z);
+      fast_normalize(x, y, z);
       cosT = fminf(cosT, dot3(cax, cay, caz, x, y, z));
     }
     cosT = cosT * (1.0f - 1e-5f) - 1e-6f;
     // a cone of 90 degrees or more (or a NaN camera) cannot cull: cos = -1 makes every ball pass
     if (!(cosT > 0.0f)) cosT = -1.0f;
-    sinT = sqrtf(fmaxf(1.0f - cosT * cosT, 0.0f)) * (1.0f + 1e-5f) + 1e-6f;
+    sinT = fast_sqrt(fmaxf(1.0f - cosT * cosT, 0.0f)) * (1.0f + 1e-5f) + 1e-6f;
     if (cosT < 0.0f) sinT = 0.0f;
   }
 
@@ -239,14 +250,14 @@ __global__ __launch_bounds__(256) void render_cull_kernel(RenderArgs A)
       while (mask) {
         const int j = __builtin_ctzll(mask);
         mask &= mask - 1;
-        const float *q = sc.tri + (base + j); // wave-uniform address: scalar loads
-        const float pnx = q[0], pny = q[nt], pnz = q[2 * nt], kp = q[3 * nt];
+        const float *q = sc.tri_rec + 16 * size_t(base + j); // wave-uniform address: one s_load_dwordx16
+        const float pnx = q[0], pny = q[1], pnz = q[2], kp = q[3];
         const float rdn = dot3(dx, dy, dz, pnx, pny, pnz);
         const float t = (kp - dot3(cam.ox, cam.oy, cam.oz, pnx, pny, pnz)) / rdn;
         const float px = cam.ox + t * dx, py = cam.oy + t * dy, pz = cam.oz + t * dz;
-        const float e0 = dot3(q[4 * nt], q[5 * nt], q[6 * nt], px, py, pz) - q[7 * nt];
-        const float e1 = dot3(q[8 * nt], q[9 * nt], q[10 * nt], px, py, pz) - q[11 * nt];
-        const float e2 = dot3(q[12 * nt], q[13 * nt], q[14 * nt], px, py, pz) - q[15 * nt];
+        const float e0 = dot3(q[4], q[5], q[6], px, py, pz) - q[7];
+        const float e1 = dot3(q[8], q[9], q[10], px, py, pz) - q[11];
+        const float e2 = dot3(q[12], q[13], q[14], px, py, pz) - q[15];
         const bool hit = (rdn != 0.0f) & (e0 > -1e-6f) & (e1 > -1e-6f) & (e2 > -1e-6f) & (0.01f <= t) & (t <= MRT_INF);
         if (hit) {
           const int obj = sc.tri_obj[base + j];
@@ -267,8 +278,8 @@ __global__ __launch_bounds__(256) void render_cull_kernel(RenderArgs A)
         normalize3(nx, ny, nz);
         hnx = nx; hny = ny; hnz = nz;
       } else {
-        const float *q = sc.tri + (best_prim - ns);
-        const float pnx = q[0], pny = q[nt], pnz = q[2 * nt];
+        const float *q = sc.tri_rec + 16 * size_t(best_prim - ns);
+        const float pnx = q[0], pny = q[1], pnz = q[2];
         const bool front = dot3(dx, dy, dz, pnx, pny, pnz) < 0;
         hnx = front ? pnx : -pnx; hny = front ? pny : -pny; hnz = front ? pnz : -pnz;
       }
@@ -282,14 +293,21 @@ __global__ __launch_bounds__(256) void render_cull_kernel(RenderArgs A)
       // ball around the tile's hit points (any subset of them is covered too)
       Bundle B;
       {
-        const float big = 3.0e38f;
-        const float lox = wave_min(have_hit ? hpx : big), hix = wave_max(have_hit ? hpx : -big);
-        const float loy = wave_min(have_hit ? hpy : big), hiy = wave_max(have_hit ? hpy : -big);
-        const float loz = wave_min(have_hit ? hpz : big), hiz = wave_max(have_hit ? hpz : -big);
-        B.mx = 0.5f * (lox + hix); B.my = 0.5f * (loy + hiy); B.mz = 0.5f * (loz + hiz);
+        if (ns + nt > 64) {
+          // many primitives: a tight ball pays for itself (centre of the hit points' box, 7 reductions)
+          const float big = 3.0e38f;
+          const float lox = wave_min(have_hit ? hpx : big), hix = wave_max(have_hit ? hpx : -big);
+          const float loy = wave_min(have_hit ? hpy : big), hiy = wave_max(have_hit ? hpy : -big);
+          const float loz = wave_min(have_hit ? hpz : big), hiz = wave_max(have_hit ? hpz : -big);
+          B.mx = 0.5f * (lox + hix); B.my = 0.5f * (loy + hiy); B.mz = 0.5f * (loz + hiz);
+        } else {
+          // few primitives: centre = the first hit lane's point (1 reduction)
+          const int first = __builtin_ctzll(__ballot(have_hit));
+          B.mx = bcast(hpx, first); B.my = bcast(hpy, first); B.mz = bcast(hpz, first);
+        }
         const float ex = hpx - B.mx, ey = hpy - B.my, ez = hpz - B.mz;
         const float e2 = have_hit ? dot3(ex, ey, ez, ex, ey, ez) : 0.0f;
-        B.rho = sqrtf(wave_max(e2)) * CULL_REL + CULL_ABS; // a NaN hit point makes every test below pass
+        B.rho = fast_sqrt(wave_max(e2)) * CULL_REL + CULL_ABS;
       }
       for (int li = 0; li < sc.nl; ++li) {
         const int lkind = sc.light_kind[li];
@@ -323,7 +341,7 @@ __global__ __launch_bounds__(256) void render_cull_kernel(RenderArgs A)
           if (i < ns) {
             cx = sc.sph_cx[i]; cy = sc.sph_cy[i]; cz = sc.sph_cz[i]; r = sc.sph_r[i];
             const float wx = cx - B.mx, wy = cy - B.my, wz = cz - B.mz;
-            const float Lm = sqrtf(dot3(wx, wy, wz, wx, wy, wz)) + B.rho; // >= |hit point - centre| in the tile
+            const float Lm = fast_sqrt(dot3(wx, wy, wz, wx, wy, wz)) * CULL_REL + B.rho; // >= |hit point - centre| in the tile
             pass = bundle_may_touch(B, cx, cy, cz, sphere_cull_radius(r * r, Lm * Lm));
           }
           unsigned long long mask = __ballot(pass);
@@ -351,14 +369,14 @@ __global__ __launch_bounds__(256) void render_cull_kernel(RenderArgs A)
           while (mask) {
             const int j = __builtin_ctzll(mask);
             mask &= mask - 1;
-            const float *q = sc.tri + (base + j);
-            const float pnx = q[0], pny = q[nt], pnz = q[2 * nt], kp = q[3 * nt];
+            const float *q = sc.tri_rec + 16 * size_t(base + j);
+            const float pnx = q[0], pny = q[1], pnz = q[2], kp = q[3];
             const float rdn = dot3(sdx, sdy, sdz, pnx, pny, pnz);
             const float t = (kp - dot3(hpx, hpy, hpz, pnx, pny, pnz)) / rdn;
             const float px = hpx + t * sdx, py = hpy + t * sdy, pz = hpz + t * sdz;
-            const float e0 = dot3(q[4 * nt], q[5 * nt], q[6 * nt], px, py, pz) - q[7 * nt];
-            const float e1 = dot3(q[8 * nt], q[9 * nt], q[10 * nt], px, py, pz) - q[11 * nt];
-            const float e2 = dot3(q[12 * nt], q[13 * nt], q[14 * nt], px, py, pz) - q[15 * nt];
+            const float e0 = dot3(q[4], q[5], q[6], px, py, pz) - q[7];
+            const float e1 = dot3(q[8], q[9], q[10], px, py, pz) - q[11];
+            const float e2 = dot3(q[12], q[13], q[14], px, py, pz) - q[15];
             const bool h = (rdn != 0.0f) & (e0 > -1e-6f) & (e1 > -1e-6f) & (e2 > -1e-6f) & (1e-3f <= t) & (t <= tl);
             if (open && h) open = false;
             if (!__any(open)) { wave_open = false; break; }

@@ -18,6 +18,9 @@ struct DevScene {
   // conservative bounding spheres of the regions the triangle hit test accepts (built at upload,
   // mrt_api.cpp tri_bound); radius +inf = never culled.  4 streams of nt floats.
   const float *tri_bx, *tri_by, *tri_bz, *tri_br;
+  // the same 16 floats per triangle, contiguous (64 B records), for wave-uniform fetches of the few
+  // triangles that survive culling (one s_load_dwordx16 instead of 16 strided scalar loads)
+  const float *tri_rec;
   int32_t nt;
   // per object material (core/material.cuh:78,160)
   const uint8_t *mat_kind;
