@@ -140,11 +140,11 @@ __global__ __launch_bounds__(256) void render_cull_kernel(RenderArgs A)
   const int tx = lane & 7, ty = lane >> 3;
   const int ns = sc.ns, nt = sc.nt;
 
-  const int tiles_x = (A.W + 7) / 8;
-  const int ntiles = tiles_x * ((A.local_rows + 7) / 8);
-  const int tile = blockIdx.x * 4 + wave;
-  if (tile >= ntiles) return; // waves are independent: no barrier anywhere below
-  const int tile_y = tile / tiles_x, tile_x = tile - tile_y * tiles_x;
+  // 2-D grid: blockIdx.y = tile row, blockIdx.x*4 + wave = tile column (both wave-uniform, so the strip
+  // arithmetic below runs on the scalar unit)
+  const int tile_x = blockIdx.x * 4 + wave;
+  const int tile_y = blockIdx.y;
+  if (tile_x * 8 >= A.W) return; // waves are independent: no barrier anywhere below
   const int col = tile_x * 8 + tx;
   const int lrow = tile_y * 8 + ty;
   // strips are multiples of 8 rows, so a tile never straddles two strips
@@ -158,8 +158,9 @@ __global__ __launch_bounds__(256) void render_cull_kernel(RenderArgs A)
   //      sub-pixel offsets of the 121-spp pattern (within (-11/13, +9/13) pixel) ----
   float cax, cay, caz, cosT = 2.0f, sinT;
   {
-    const float ulo = float(tile_x * 8 - 1) / float(A.W), uhi = float(tile_x * 8 + 8) / float(A.W);
-    const float vlo = float(grow0 - 1) / float(A.H), vhi = float(grow0 + 8) / float(A.H);
+    const float rw = fast_rcp(float(A.W)), rh = fast_rcp(float(A.H)); // bound arithmetic: approximate is fine
+    const float ulo = float(tile_x * 8 - 1) * rw, uhi = float(tile_x * 8 + 8) * rw;
+    const float vlo = float(grow0 - 1) * rh, vhi = float(grow0 + 8) * rh;
     const float um = 0.5f * (ulo + uhi), vm = 0.5f * (vlo + vhi);
     cax = ((cam.ux + um * cam.hx) + vm * cam.vx) - cam.ox;
     cay = ((cam.uy + um * cam.hy) + vm * cam.vy) - cam.oy;
@@ -448,9 +449,9 @@ __global__ __launch_bounds__(256) void render_cull_kernel(RenderArgs A)
 
 hipError_t launch_render_cull(const RenderArgs &A, hipStream_t stream)
 {
-  const int ntiles = ((A.W + 7) / 8) * ((A.local_rows + 7) / 8);
-  if (ntiles == 0) return hipSuccess;
-  hipLaunchKernelGGL(render_cull_kernel, dim3((ntiles + 3) / 4), dim3(256), 0, stream, A);
+  const int tiles_x = (A.W + 7) / 8, tiles_y = (A.local_rows + 7) / 8;
+  if (tiles_x == 0 || tiles_y == 0) return hipSuccess;
+  hipLaunchKernelGGL(render_cull_kernel, dim3((tiles_x + 3) / 4, tiles_y), dim3(256), 0, stream, A);
   return hipGetLastError();
 }
 
