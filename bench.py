@@ -112,6 +112,7 @@ def main():
     ap.add_argument("--config", default="C2")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-ids", action="store_true", help="write RGB only (12 B/pixel)")
+    ap.add_argument("--brute-force", action="store_true", help="use the every-ray-every-primitive kernel")
     args = ap.parse_args()
 
     import torch
@@ -140,6 +141,7 @@ def main():
 
     fr = multigpu.FrameRenderer(flat, cam12, W, H, rank=rank, num_ranks=world, device=local_rank,
                                 with_ids=not args.no_ids)
+    fr.ctx.set_cull(not args.brute_force)
     bytes_pp = 12 if args.no_ids else BYTES_PER_PIXEL
 
     # rays per frame (deterministic for a scene + camera): counted once, outside the timed region
@@ -159,14 +161,20 @@ def main():
     for _ in range(warmup):
         fr.step()
     sync()
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+    # HIP events on the stream the kernel is launched on (torch's current stream), around the render
+    # kernel only (the gather/assembly follow the second event).  Every 8th step is sampled so that
+    # recording does not open gaps between the back-to-back launches of a frame that lasts ~30 us.
+    stride = 8 if steps >= 64 else 1
+    ev = {k: (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+          for k in range(0, steps, stride)}
     t0 = time.perf_counter()
     for k in range(steps):
-        # HIP events on the stream the kernel is launched on (torch's current stream), around the
-        # render kernel only: the gather/assembly of step() follow the second event
-        ev[k][0].record()
+        e = ev.get(k)
+        if e:
+            e[0].record()
         fr.render_local()
-        ev[k][1].record()
+        if e:
+            e[1].record()
         if world > 1:
             multigpu.gather_strips(fr.rgb, world, rank, dst=0, out=fr.gathered)
             if rank == 0:
@@ -178,7 +186,7 @@ def main():
     if world > 1:
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
     elapsed = float(el.item())
-    kern_ms = sum(a.elapsed_time(b) for a, b in ev) / steps
+    kern_ms = sum(a.elapsed_time(b) for a, b in ev.values()) / len(ev)
 
     if rank == 0:
         ms_per_step = elapsed / steps * 1e3
@@ -200,11 +208,13 @@ def main():
                        "primary_rays": primary, "shadow_rays": shadow,
                        "parallelism": f"{world} GPU(s): 8-row strips round-robin, scene replicated" +
                                       ("" if world == 1 else ", RCCL gather to rank 0 + strip assembly"),
-                       "outputs": "rgb f32 + id i32 + t f32" if not args.no_ids else "rgb f32"},
+                       "outputs": "rgb f32 + id i32 + t f32" if not args.no_ids else "rgb f32",
+                       "kernel": "render_cull_kernel (tile culling + exact tests)" if fr.ctx.cull else
+                                 "render_kernel (brute force)"},
             "roofline": {"bound": "hbm", "achieved": round(ach_gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(ach_gbs / HBM_PEAK_GBS, 5),
                          "traffic": measured_traffic(args.config, alg_bytes) if world == 1 else None,
-                         "kernel": "render_kernel", "kernel_ms": round(kern_ms, 5),
+                         "kernel": "render_cull_kernel" if fr.ctx.cull else "render_kernel", "kernel_ms": round(kern_ms, 5),
                          "algorithmic_bytes_per_launch": alg_bytes},
             "roofline_valu": {"bound": "fp32 vector ALU (no MFMA: no dense contraction)",
                               "achieved": round(ach_tf, 4), "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s",

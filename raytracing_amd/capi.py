@@ -273,6 +273,7 @@ class Context:
             raise MrtError(f"mrt_ctx_create({device}): {rc} {self._L.mrt_last_error(None).decode()}")
         self._h = h
         self.device = device
+        self.cull = os.environ.get("MRT_CULL", "1")[:1] != "0"
 
     def close(self):
         if getattr(self, "_h", None):
@@ -299,6 +300,7 @@ class Context:
     def set_cull(self, on):
         """True: tile-culling kernel (default); False: brute-force kernel.  Identical outputs."""
         self._check(self._L.mrt_ctx_set_option(self._h, 1, 1 if on else 0), "mrt_ctx_set_option")
+        self.cull = bool(on)
 
     def upload(self, flat):
         d = flat.desc()

@@ -23,6 +23,7 @@
 #include "mrt_internal.h"
 #include "mrt_device.h"
 
+#include <cmath>
 #include <cstdlib>
 
 namespace mrt {
@@ -156,30 +157,22 @@ __global__ __launch_bounds__(256) void render_cull_kernel(RenderArgs A)
 
   // ---- cone around the tile's rays.  Corners one pixel outside the tile, which also covers the
   //      sub-pixel offsets of the 121-spp pattern (within (-11/13, +9/13) pixel) ----
-  float cax, cay, caz, cosT = 2.0f, sinT;
+  // d(u,v) is affine in (u,v), so every ray of the (padded) tile is the centre ray plus an offset of norm
+  // <= cone_ext (half a padded tile in u and v, computed by the launcher): the angle to the centre ray is
+  // at most asin(cone_ext / |centre ray|).
+  float cax, cay, caz, cosT, sinT;
   {
     const float rw = fast_rcp(float(A.W)), rh = fast_rcp(float(A.H)); // bound arithmetic: approximate is fine
-    const float ulo = float(tile_x * 8 - 1) * rw, uhi = float(tile_x * 8 + 8) * rw;
-    const float vlo = float(grow0 - 1) * rh, vhi = float(grow0 + 8) * rh;
-    const float um = 0.5f * (ulo + uhi), vm = 0.5f * (vlo + vhi);
+    const float um = (float(tile_x * 8) + 3.5f) * rw, vm = (float(grow0) + 3.5f) * rh;
     cax = ((cam.ux + um * cam.hx) + vm * cam.vx) - cam.ox;
     cay = ((cam.uy + um * cam.hy) + vm * cam.vy) - cam.oy;
     caz = ((cam.uz + um * cam.hz) + vm * cam.vz) - cam.oz;
-    fast_normalize(cax, cay, caz);
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const float su = (k & 1) ? uhi : ulo, sv = (k & 2) ? vhi : vlo;
-      float x = ((cam.ux + su * cam.hx) + sv * cam.vx) - cam.ox;
-      float y = ((cam.uy + su * cam.hy) + sv * cam.vy) - cam.oy;
-      float z = ((cam.uz + su * cam.hz) + sv * cam.vz) - cam.oz;
-      fast_normalize(x, y, z);
-      cosT = fminf(cosT, dot3(cax, cay, caz, x, y, z));
-    }
-    cosT = cosT * (1.0f - 1e-5f) - 1e-6f;
+    const float inv = fast_rsq(dot3(cax, cay, caz, cax, cay, caz));
+    cax *= inv; cay *= inv; caz *= inv;
+    sinT = A.cone_ext * inv * (1.0f + 1e-4f) + 1e-6f;
+    cosT = fast_sqrt(fmaxf(1.0f - sinT * sinT, 0.0f)) * (1.0f - 1e-5f) - 1e-6f;
     // a cone of 90 degrees or more (or a NaN camera) cannot cull: cos = -1 makes every ball pass
-    if (!(cosT > 0.0f)) cosT = -1.0f;
-    sinT = fast_sqrt(fmaxf(1.0f - cosT * cosT, 0.0f)) * (1.0f + 1e-5f) + 1e-6f;
-    if (cosT < 0.0f) sinT = 0.0f;
+    if (!(sinT < 0.99f) || !(cosT > 0.0f)) { cosT = -1.0f; sinT = 0.0f; }
   }
 
   float accr = 0.0f, accg = 0.0f, accb = 0.0f;
@@ -447,8 +440,18 @@ __global__ __launch_bounds__(256) void render_cull_kernel(RenderArgs A)
   }
 }
 
-hipError_t launch_render_cull(const RenderArgs &A, hipStream_t stream)
+hipError_t launch_render_cull(const RenderArgs &in, hipStream_t stream)
 {
+  RenderArgs A = in;
+  // largest offset of a ray of the padded tile (pixels -1..8, i.e. +-4.5 around the centre 3.5) from the
+  // tile's centre ray: max |+-4.5/W hor +- 4.5/H ver|, in double, rounded up
+  {
+    const double hx[3] = {4.5 / A.W * A.cam.hx, 4.5 / A.W * A.cam.hy, 4.5 / A.W * A.cam.hz};
+    const double hy[3] = {4.5 / A.H * A.cam.vx, 4.5 / A.H * A.cam.vy, 4.5 / A.H * A.cam.vz};
+    double p = 0, m = 0;
+    for (int k = 0; k < 3; ++k) { p += (hx[k] + hy[k]) * (hx[k] + hy[k]); m += (hx[k] - hy[k]) * (hx[k] - hy[k]); }
+    A.cone_ext = float(std::sqrt(p > m ? p : m) * 1.001);
+  }
   const int tiles_x = (A.W + 7) / 8, tiles_y = (A.local_rows + 7) / 8;
   if (tiles_x == 0 || tiles_y == 0) return hipSuccess;
   hipLaunchKernelGGL(render_cull_kernel, dim3((tiles_x + 3) / 4, tiles_y), dim3(256), 0, stream, A);

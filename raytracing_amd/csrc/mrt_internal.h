@@ -54,6 +54,7 @@ struct RenderArgs {
   // LDS plan (filled by the launcher)
   int32_t resident;                 // whole scene staged once
   int32_t s_cap, t_cap;             // primitives per LDS chunk
+  float cone_ext;                   // cull kernel: max |ray - tile centre ray| over a padded tile (launcher)
 };
 
 hipError_t launch_render_cull(const RenderArgs &args, hipStream_t stream);
