@@ -141,7 +141,7 @@ def main():
 
     fr = multigpu.FrameRenderer(flat, cam12, W, H, rank=rank, num_ranks=world, device=local_rank,
                                 with_ids=not args.no_ids)
-    fr.ctx.set_cull(not args.brute_force)
+    fr.ctx.set_cull(0 if args.brute_force else 1)
     bytes_pp = 12 if args.no_ids else BYTES_PER_PIXEL
 
     # rays per frame (deterministic for a scene + camera): counted once, outside the timed region
@@ -209,12 +209,12 @@ def main():
                        "parallelism": f"{world} GPU(s): 8-row strips round-robin, scene replicated" +
                                       ("" if world == 1 else ", RCCL gather to rank 0 + strip assembly"),
                        "outputs": "rgb f32 + id i32 + t f32" if not args.no_ids else "rgb f32",
-                       "kernel": "render_cull_kernel (tile culling + exact tests)" if fr.ctx.cull else
+                       "kernel": "tile culling + exact tests (automatic choice of 1 or 2 levels)" if fr.ctx.cull else
                                  "render_kernel (brute force)"},
             "roofline": {"bound": "hbm", "achieved": round(ach_gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(ach_gbs / HBM_PEAK_GBS, 5),
                          "traffic": measured_traffic(args.config, alg_bytes) if world == 1 else None,
-                         "kernel": "render_cull_kernel" if fr.ctx.cull else "render_kernel", "kernel_ms": round(kern_ms, 5),
+                         "kernel": "render_cull*_kernel" if fr.ctx.cull else "render_kernel", "kernel_ms": round(kern_ms, 5),
                          "algorithmic_bytes_per_launch": alg_bytes},
             "roofline_valu": {"bound": "fp32 vector ALU (no MFMA: no dense contraction)",
                               "achieved": round(ach_tf, 4), "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s",

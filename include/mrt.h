@@ -121,9 +121,10 @@ const char *mrt_last_error(const mrt_ctx *ctx);
 const char *mrt_status_string(int status);
 
 /*
- * Context options (no reference counterpart).  MRT_OPT_CULL: 1 (default, or environment MRT_CULL) renders
- * with the tile-culling kernel; 0 with the brute-force kernel that, like the reference loops
- * (src/main.cu:67-77), tests every ray against every primitive.  Both produce identical buffers.
+ * Context options (no reference counterpart).  MRT_OPT_CULL (default 1, or environment MRT_CULL) picks the
+ * render kernel: 0 = brute force, which like the reference loops (src/main.cu:67-77) tests every ray against
+ * every primitive; 1 = automatic; 2 = one-level tile culling; 3 / 4 = two-level tile culling with 4 / 8 waves
+ * per workgroup.  All kernels produce identical buffers.
  */
 enum { MRT_OPT_CULL = 1 };
 int mrt_ctx_set_option(mrt_ctx *ctx, int option, int value);

@@ -273,7 +273,7 @@ class Context:
             raise MrtError(f"mrt_ctx_create({device}): {rc} {self._L.mrt_last_error(None).decode()}")
         self._h = h
         self.device = device
-        self.cull = os.environ.get("MRT_CULL", "1")[:1] != "0"
+        self.cull = int(os.environ.get("MRT_CULL", "1"))
 
     def close(self):
         if getattr(self, "_h", None):
@@ -297,10 +297,12 @@ class Context:
             raise MrtError(f"{what}: {rc} ({self._L.mrt_status_string(rc).decode()}) "
                            f"{self._L.mrt_last_error(self._h).decode()}")
 
-    def set_cull(self, on):
-        """True: tile-culling kernel (default); False: brute-force kernel.  Identical outputs."""
-        self._check(self._L.mrt_ctx_set_option(self._h, 1, 1 if on else 0), "mrt_ctx_set_option")
-        self.cull = bool(on)
+    def set_cull(self, mode):
+        """Render kernel: 0/False brute force, 1/True automatic (default), 2 one-level culling,
+        3 / 4 two-level culling with 4 / 8 waves.  Identical outputs."""
+        mode = int(mode)
+        self._check(self._L.mrt_ctx_set_option(self._h, 1, mode), "mrt_ctx_set_option")
+        self.cull = mode
 
     def upload(self, flat):
         d = flat.desc()

@@ -33,7 +33,7 @@ struct mrt_ctx {
   void *out_mem = nullptr;
   size_t out_bytes = 0;
   unsigned long long *stats_dev = nullptr;
-  bool cull = true;
+  int cull = 1; // MRT_OPT_CULL value
 };
 
 static thread_local std::string g_create_err;
@@ -57,12 +57,31 @@ static int hip_fail(mrt_ctx *ctx, hipError_t e, const char *what)
     if (e_ != hipSuccess) return hip_fail((ctx), e_, #expr); \
   } while (0)
 
-// MRT_CULL=0 selects the brute-force LDS kernel (every ray x every primitive); the default kernel culls
-// primitives per tile first and produces identical buffers (tests compare the two).
-static bool use_cull()
+// Kernel choice (MRT_OPT_CULL / environment MRT_CULL): 0 brute force (every ray x every primitive, like the
+// reference loops), 1 automatic (default), 2 one-level tile culling, 3 / 4 two-level culling with 4 / 8 waves.
+// All of them produce identical buffers (tests compare them).
+static int use_cull()
 {
-  static const bool v = [] { const char *e = getenv("MRT_CULL"); return !(e && e[0] == '0'); }();
+  static const int v = [] {
+    const char *e = getenv("MRT_CULL");
+    const int x = e ? atoi(e) : 1;
+    return (x < 0 || x > 4) ? 1 : x;
+  }();
   return v;
+}
+
+static hipError_t launch_by_mode(int mode, const mrt::RenderArgs &A, hipStream_t st)
+{
+  if (mode == 1) {
+    const long n = (long)A.sc.ns + A.sc.nt;
+    mode = n >= 100000 ? 4 : (n >= 1024 ? 3 : 2);
+  }
+  switch (mode) {
+  case 0: return mrt::launch_render(A, st);
+  case 2: return mrt::launch_render_cull(A, st);
+  case 3: return mrt::launch_render_cull2(A, 4, st);
+  default: return mrt::launch_render_cull2(A, 8, st);
+  }
 }
 
 extern "C" {
@@ -70,7 +89,11 @@ extern "C" {
 int mrt_ctx_set_option(mrt_ctx *ctx, int option, int value)
 {
   if (!ctx) return MRT_ERR_INVALID;
-  if (option == MRT_OPT_CULL) { ctx->cull = value != 0; return MRT_OK; }
+  if (option == MRT_OPT_CULL) {
+    if (value < 0 || value > 4) return fail(ctx, MRT_ERR_INVALID, "MRT_OPT_CULL takes 0..4");
+    ctx->cull = value;
+    return MRT_OK;
+  }
   return fail(ctx, MRT_ERR_INVALID, "unknown option");
 }
 
@@ -337,7 +360,7 @@ int mrt_render_device(mrt_ctx *ctx, const mrt_camera *cam, const mrt_render_para
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   hipStream_t st = (hipStream_t)stream; // NULL = HIP's default stream, as everywhere in HIP
   if (A.stats) HIP_TRY(ctx, hipMemsetAsync(A.stats, 0, 4 * sizeof(unsigned long long), st));
-  HIP_TRY(ctx, ctx->cull ? mrt::launch_render_cull(A, st) : mrt::launch_render(A, st));
+  HIP_TRY(ctx, launch_by_mode(ctx->cull, A, st));
   return MRT_OK;
 }
 
@@ -363,7 +386,7 @@ int mrt_render(mrt_ctx *ctx, const mrt_camera *cam, const mrt_render_params *par
   A.stats = stats ? ctx->stats_dev : nullptr;
   if (A.stats) HIP_TRY(ctx, hipMemsetAsync(A.stats, 0, 4 * sizeof(unsigned long long), ctx->stream));
   HIP_TRY(ctx, hipEventRecord(ctx->ev0, ctx->stream));
-  HIP_TRY(ctx, ctx->cull ? mrt::launch_render_cull(A, ctx->stream) : mrt::launch_render(A, ctx->stream));
+  HIP_TRY(ctx, launch_by_mode(ctx->cull, A, ctx->stream));
   HIP_TRY(ctx, hipEventRecord(ctx->ev1, ctx->stream));
   if (npix) {
     HIP_TRY(ctx, hipMemcpyAsync(rgb, A.rgb, npix * 12, hipMemcpyDeviceToHost, ctx->stream));

@@ -58,6 +58,8 @@ struct RenderArgs {
 };
 
 hipError_t launch_render_cull(const RenderArgs &args, hipStream_t stream);
+// two-level culling (mrt_cull2.hip); waves = 4 (32x32-pixel super-tiles) or 8 (64x32)
+hipError_t launch_render_cull2(const RenderArgs &args, int waves, hipStream_t stream);
 
 // launchers (mrt_kernels.hip)
 hipError_t launch_render(const RenderArgs &args, hipStream_t stream);

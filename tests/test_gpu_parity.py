@@ -19,13 +19,16 @@ GOLD = os.path.join(os.path.dirname(__file__), "golden")
 RGB_TOL = 1.0 / 255.0
 
 
-@pytest.fixture(params=["cull", "brute"], autouse=True)
+KERNEL_MODES = {"brute": 0, "cull": 2, "cull2x4": 3, "cull2x8": 4}
+
+
+@pytest.fixture(params=list(KERNEL_MODES), autouse=True)
 def kernel_mode(request, gpu_ctx):
-    """Every test runs against both render kernels: the tile-culling one (default) and the brute-force
-    one that walks every primitive for every ray like the reference loops."""
-    gpu_ctx.set_cull(request.param == "cull")
+    """Every test runs against every render kernel: brute force (walks every primitive for every ray like
+    the reference loops), one-level tile culling, two-level tile culling with 4 and 8 waves."""
+    gpu_ctx.set_cull(KERNEL_MODES[request.param])
     yield request.param
-    gpu_ctx.set_cull(True)
+    gpu_ctx.set_cull(1)
 
 
 def _load(name):
@@ -302,13 +305,13 @@ def test_multisample_121_mode(gpu_ctx):
 
 # ------------------------------------------------------------------ culling never changes a result
 
-def _render_both(ctx, cam, W, H, **kw):
-    ctx.set_cull(True)
-    a = ctx.render(cam, W, H, **kw)
-    ctx.set_cull(False)
-    b = ctx.render(cam, W, H, **kw)
-    ctx.set_cull(True)
-    return a, b
+def _render_modes(ctx, cam, W, H, modes, **kw):
+    out = []
+    for m in modes:
+        ctx.set_cull(m)
+        out.append(ctx.render(cam, W, H, **kw))
+    ctx.set_cull(1)
+    return out
 
 
 def _assert_same(a, b, what):
@@ -323,7 +326,7 @@ def test_culling_matches_brute_force_at_full_size(gpu_ctx, kernel_mode, name):
     """Size-independent property at BASELINE.json's full frame sizes, where the oracle is too slow:
     the culled kernel and the every-ray-every-primitive kernel must agree bit for bit."""
     if kernel_mode != "cull":
-        pytest.skip("compares both kernels itself")
+        pytest.skip("compares the kernels itself")
     if name == "C3_spheres_4k":
         spec, (W, H) = scenes.sphere_field(10000), (3840, 2160)
     elif name == "C5_lights_1080p":
@@ -331,9 +334,10 @@ def test_culling_matches_brute_force_at_full_size(gpu_ctx, kernel_mode, name):
     else:
         spec, (W, H) = scenes.triangle_terrain(200, 100), (1920, 1080)
     gpu_ctx.upload(spec.flatten())
-    a, b = _render_both(gpu_ctx, spec.cam12(W / H), W, H)
-    _assert_same(a, b, name)
-    assert a["stats"]["hit_pixels"] > 10000
+    brute, one, two4, two8, auto = _render_modes(gpu_ctx, spec.cam12(W / H), W, H, (0, 2, 3, 4, 1))
+    for other, label in ((one, "one-level"), (two4, "two-level x4"), (two8, "two-level x8"), (auto, "automatic")):
+        _assert_same(other, brute, f"{name} {label}")
+    assert brute["stats"]["hit_pixels"] > 10000
 
 
 def _random_scene(seed):

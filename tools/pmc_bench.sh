@@ -16,7 +16,7 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
     f = glob.glob("$out/${tag}_%s*counter_collection.csv" % c)[0]
     tot, n = 0.0, 0
     for r in csv.DictReader(open(f)):
-        if "render_kernel" in r["Kernel_Name"] and r["Counter_Name"] == c:
+        if "render_" in r["Kernel_Name"] and r["Counter_Name"] == c:
             tot += float(r["Counter_Value"]); n += 1
     res[c] = {"mean_per_dispatch_KB": tot / max(n, 1), "dispatches": n}
 print(json.dumps(res))
