@@ -74,7 +74,7 @@ static hipError_t launch_by_mode(int mode, const mrt::RenderArgs &A, hipStream_t
 {
   if (mode == 1) {
     const long n = (long)A.sc.ns + A.sc.nt;
-    mode = n >= 100000 ? 4 : (n >= 1024 ? 3 : 2);
+    mode = n >= 50000 ? 4 : 2; // measured: two levels pay from ~50k primitives
   }
   switch (mode) {
   case 0: return mrt::launch_render(A, st);

@@ -23,7 +23,9 @@
 
 namespace mrt {
 
-constexpr int CULL2_CAP = 8192; // primitives per level-1 chunk = capacity of the LDS survivor list (32 KiB)
+constexpr int CULL2_CAP = 8192;   // capacity of the LDS survivor list (32 KiB)
+constexpr int CULL2_SPAN = 16384; // primitives per level-1 pass; a pass whose survivors overflow the list is
+                                  // redone in spans of CULL2_CAP, which always fit
 constexpr int TPW = 4;          // tiles per wave
 
 // append the lanes with pass == true to the LDS list
@@ -34,7 +36,34 @@ __device__ __forceinline__ void list_append(int *list, int *count, bool pass, in
   int base = 0;
   if (lane == 0) base = atomicAdd(count, __popcll(mask));
   base = __builtin_amdgcn_readfirstlane(base);
-  if (pass) list[base + __popcll(mask & ((1ull << lane) - 1ull))] = value;
+  const int slot = base + __popcll(mask & ((1ull << lane) - 1ull));
+  if (pass && slot < CULL2_CAP) list[slot] = value; // the counter still counts: overflow is detected by the caller
+}
+
+// Level 1 over primitives [c0, cend): every thread of the workgroup takes one primitive per step, 4 steps
+// per iteration with all 16 loads issued before the first test (the loop is latency-bound otherwise).
+// bx..br are the bound streams (sphere centre + radius, or triangle bounding sphere); test(x,y,z,r) -> pass.
+template <int NT, class Test>
+__device__ __forceinline__ void level1_pass(const float *__restrict__ bx, const float *__restrict__ by,
+                                            const float *__restrict__ bz, const float *__restrict__ br, int c0,
+                                            int cend, int wave, int lane, int *list, int *count, Test test)
+{
+  constexpr int U = 4;
+  for (int b = c0 + wave * 64; b < cend; b += NT * U) {
+    float x[U], y[U], z[U], r[U];
+    int idx[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      idx[u] = b + u * NT + lane;
+      const int ii = min(idx[u], cend - 1);
+      x[u] = bx[ii]; y[u] = by[ii]; z[u] = bz[ii]; r[u] = br[ii];
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const bool pass = (idx[u] < cend) && test(x[u], y[u], z[u], r[u]);
+      list_append(list, count, pass, idx[u], lane);
+    }
+  }
 }
 
 struct Cone { float ax, ay, az, cosT, sinT; };
@@ -151,23 +180,19 @@ __global__ __launch_bounds__(WAVES * 64) void render_cull2_kernel(RenderArgs A)
     }
 
     // ---- closest hit over spheres: src/main.cu:60-77, core/sphere.cuh:32-73, interval [0.01, inf] ----
-    for (int c0 = 0; c0 < ns; c0 += CULL2_CAP) {
-      const int cend = min(ns, c0 + CULL2_CAP);
+    for (int c0 = 0, span = CULL2_SPAN; c0 < ns;) {
+      const int cend = min(ns, c0 + span);
       if (tid == 0) s_count = 0;
       __syncthreads();
-      for (int b = c0 + wave * 64; b < cend; b += NT) { // level 1
-        const int i = b + lane;
-        bool pass = false;
-        if (i < cend) {
-          const float r = sc.sph_r[i];
-          const float wx = sc.sph_cx[i] - cam.ox, wy = sc.sph_cy[i] - cam.oy, wz = sc.sph_cz[i] - cam.oz;
-          pass = ball_may_touch_cone(wx, wy, wz, sphere_cull_radius(r * r, dot3(wx, wy, wz, wx, wy, wz)), SC.ax, SC.ay,
-                                     SC.az, SC.cosT, SC.sinT);
-        }
-        list_append(s_list, &s_count, pass, i, lane);
-      }
+      level1_pass<NT>(sc.sph_cx, sc.sph_cy, sc.sph_cz, sc.sph_r, c0, cend, wave, lane, s_list, &s_count,
+                      [&](float cx, float cy, float cz, float r) {
+                        const float wx = cx - cam.ox, wy = cy - cam.oy, wz = cz - cam.oz;
+                        return ball_may_touch_cone(wx, wy, wz, sphere_cull_radius(r * r, dot3(wx, wy, wz, wx, wy, wz)),
+                                                   SC.ax, SC.ay, SC.az, SC.cosT, SC.sinT);
+                      });
       __syncthreads();
       const int cnt = s_count;
+      if (cnt > CULL2_CAP) { span = CULL2_CAP; __syncthreads(); continue; } // overflow: redo in spans that fit
       for (int lb = 0; lb < cnt; lb += 64) { // level 2
         const int e = lb + lane;
         int idx = 0;
@@ -205,25 +230,22 @@ __global__ __launch_bounds__(WAVES * 64) void render_cull2_kernel(RenderArgs A)
         }
       }
       __syncthreads();
+      c0 = cend; span = CULL2_SPAN;
     }
 
     // ---- closest hit over triangles: core/triangle.cuh:77-103 ----
-    for (int c0 = 0; c0 < nt; c0 += CULL2_CAP) {
-      const int cend = min(nt, c0 + CULL2_CAP);
+    for (int c0 = 0, span = CULL2_SPAN; c0 < nt;) {
+      const int cend = min(nt, c0 + span);
       if (tid == 0) s_count = 0;
       __syncthreads();
-      for (int b = c0 + wave * 64; b < cend; b += NT) { // level 1
-        const int i = b + lane;
-        bool pass = false;
-        if (i < cend) {
-          const float wx = sc.tri_bx[i] - cam.ox, wy = sc.tri_by[i] - cam.oy, wz = sc.tri_bz[i] - cam.oz;
-          pass = ball_may_touch_cone(wx, wy, wz, sc.tri_br[i] * CULL_REL + CULL_ABS, SC.ax, SC.ay, SC.az, SC.cosT,
-                                     SC.sinT);
-        }
-        list_append(s_list, &s_count, pass, i, lane);
-      }
+      level1_pass<NT>(sc.tri_bx, sc.tri_by, sc.tri_bz, sc.tri_br, c0, cend, wave, lane, s_list, &s_count,
+                      [&](float bx, float by, float bz, float br) {
+                        return ball_may_touch_cone(bx - cam.ox, by - cam.oy, bz - cam.oz, br * CULL_REL + CULL_ABS, SC.ax,
+                                                   SC.ay, SC.az, SC.cosT, SC.sinT);
+                      });
       __syncthreads();
       const int cnt = s_count;
+      if (cnt > CULL2_CAP) { span = CULL2_CAP; __syncthreads(); continue; }
       for (int lb = 0; lb < cnt; lb += 64) { // level 2
         const int e = lb + lane;
         int idx = 0;
@@ -261,6 +283,7 @@ __global__ __launch_bounds__(WAVES * 64) void render_cull2_kernel(RenderArgs A)
         }
       }
       __syncthreads();
+      c0 = cend; span = CULL2_SPAN;
     }
 
     // ---- hit records (core/sphere.cuh:45-47, core/triangle.cuh:96-97) ----
@@ -371,26 +394,22 @@ __global__ __launch_bounds__(WAVES * 64) void render_cull2_kernel(RenderArgs A)
         SB.DD = dot3(SB.Dx, SB.Dy, SB.Dz, SB.Dx, SB.Dy, SB.Dz);
 
         // any-hit over spheres, interval [1e-3, t_light] (core/light.cuh:28-33)
-        for (int c0 = 0; c0 < ns; c0 += CULL2_CAP) {
+        for (int c0 = 0, span = CULL2_SPAN; c0 < ns;) {
           any_open = false;
 #pragma unroll
           for (int k = 0; k < TPW; ++k) any_open |= open[k];
           if (tid == 0) s_count = 0;
           if (!__syncthreads_or(any_open ? 1 : 0)) break; // nobody in the workgroup has an undecided ray
-          const int cend = min(ns, c0 + CULL2_CAP);
-          for (int b = c0 + wave * 64; b < cend; b += NT) { // level 1
-            const int i = b + lane;
-            bool pass = false;
-            if (i < cend) {
-              const float cx = sc.sph_cx[i], cy = sc.sph_cy[i], cz = sc.sph_cz[i], r = sc.sph_r[i];
-              const float wx = cx - SB.mx, wy = cy - SB.my, wz = cz - SB.mz;
-              const float Lm = fast_sqrt(dot3(wx, wy, wz, wx, wy, wz)) * CULL_REL + SB.rho;
-              pass = bundle_may_touch(SB, cx, cy, cz, sphere_cull_radius(r * r, Lm * Lm));
-            }
-            list_append(s_list, &s_count, pass, i, lane);
-          }
+          const int cend = min(ns, c0 + span);
+          level1_pass<NT>(sc.sph_cx, sc.sph_cy, sc.sph_cz, sc.sph_r, c0, cend, wave, lane, s_list, &s_count,
+                          [&](float cx, float cy, float cz, float r) {
+                            const float wx = cx - SB.mx, wy = cy - SB.my, wz = cz - SB.mz;
+                            const float Lm = fast_sqrt(dot3(wx, wy, wz, wx, wy, wz)) * CULL_REL + SB.rho;
+                            return bundle_may_touch(SB, cx, cy, cz, sphere_cull_radius(r * r, Lm * Lm));
+                          });
           __syncthreads();
           const int cnt = s_count;
+          if (cnt > CULL2_CAP) { span = CULL2_CAP; __syncthreads(); continue; }
           for (int lb = 0; lb < cnt; lb += 64) { // level 2
             const int e = lb + lane;
             float cx = 0.0f, cy = 0.0f, cz = 0.0f, r = 0.0f;
@@ -425,23 +444,21 @@ __global__ __launch_bounds__(WAVES * 64) void render_cull2_kernel(RenderArgs A)
             }
           }
           __syncthreads();
+          c0 = cend; span = CULL2_SPAN;
         }
         // any-hit over triangles
-        for (int c0 = 0; c0 < nt; c0 += CULL2_CAP) {
+        for (int c0 = 0, span = CULL2_SPAN; c0 < nt;) {
           any_open = false;
 #pragma unroll
           for (int k = 0; k < TPW; ++k) any_open |= open[k];
           if (tid == 0) s_count = 0;
           if (!__syncthreads_or(any_open ? 1 : 0)) break;
-          const int cend = min(nt, c0 + CULL2_CAP);
-          for (int b = c0 + wave * 64; b < cend; b += NT) { // level 1
-            const int i = b + lane;
-            bool pass = false;
-            if (i < cend) pass = bundle_may_touch(SB, sc.tri_bx[i], sc.tri_by[i], sc.tri_bz[i], sc.tri_br[i]);
-            list_append(s_list, &s_count, pass, i, lane);
-          }
+          const int cend = min(nt, c0 + span);
+          level1_pass<NT>(sc.tri_bx, sc.tri_by, sc.tri_bz, sc.tri_br, c0, cend, wave, lane, s_list, &s_count,
+                          [&](float bx, float by, float bz, float br) { return bundle_may_touch(SB, bx, by, bz, br); });
           __syncthreads();
           const int cnt = s_count;
+          if (cnt > CULL2_CAP) { span = CULL2_CAP; __syncthreads(); continue; }
           for (int lb = 0; lb < cnt; lb += 64) { // level 2
             const int e = lb + lane;
             int idx = 0;
@@ -473,6 +490,7 @@ __global__ __launch_bounds__(WAVES * 64) void render_cull2_kernel(RenderArgs A)
             }
           }
           __syncthreads();
+          c0 = cend; span = CULL2_SPAN;
         }
 
         // light_bounce with the LIGHT's normal, as the reference passes it (core/light.cuh:164-168)

@@ -340,6 +340,26 @@ def test_culling_matches_brute_force_at_full_size(gpu_ctx, kernel_mode, name):
     assert brute["stats"]["hit_pixels"] > 10000
 
 
+def test_dense_cluster_overflows_the_survivor_list(gpu_ctx):
+    """12 000 small spheres and 9 000+ small triangles inside one super-tile: the level-1 survivor list of the
+    two-level kernels (8192 entries) overflows and the pass is redone in spans that fit."""
+    sp = scenes.random_spheres(12000, seed=7, box=((-0.6, 0.6), (-0.4, 0.4), (-26.0, -22.0)), radii=(0.004, 0.012))
+    tv = scenes.terrain_triangles(96, 48, x_range=(-0.6, 0.6), z_range=(-26.0, -22.0), amp=0.05, y0=-0.45)
+    n = len(sp) + len(tv)
+    kind, rgb = scenes._cycle_materials(n)
+    spec = scenes.SceneSpec("cluster", sp, np.arange(len(sp)), tv, len(sp) + np.arange(len(tv)), kind, rgb,
+                            [(capi.LIGHT_DIRECTIONAL, (0.2, -1.0, -0.3), (4.0, 4.0, 4.0)),
+                             (capi.LIGHT_POINT, (0.0, 3.0, -24.0), (1.0, 1.0, 1.0))], scenes._camera(20.0))
+    gpu_ctx.upload(spec.flatten())
+    W, H = 160, 96
+    cam = spec.cam12(W / H)
+    g = gpu_ctx.render(cam, W, H)
+    r = O.Scene.from_spec(spec).render(cam, W, H, nthreads=8)
+    assert_frame_parity(g, r, "cluster")
+    assert_stats_parity(g["stats"], r["stats"])
+    assert g["stats"]["hit_pixels"] > 50 and g["stats"]["shadow_rays"] > 50
+
+
 def _random_scene(seed):
     """Adversarial mix for the culling bounds: radii over 5 decades, spheres around and behind the
     camera, slivers, triangles whose plane passes through the world origin (degenerate edge planes:
