@@ -12,6 +12,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <algorithm>
 #include <cstring>
 #include <new>
 #include <string>
@@ -81,6 +82,81 @@ static hipError_t launch_by_mode(int mode, const mrt::RenderArgs &A, hipStream_t
   case 2: return mrt::launch_render_cull(A, st);
   case 3: return mrt::launch_render_cull2(A, 4, st);
   default: return mrt::launch_render_cull2(A, 8, st);
+  }
+}
+
+// ---- primitive-side hierarchy (camera independent, built once per upload) ----
+// Primitives of each type are stored in Morton order of their bound centres, and every run of 64 consecutive
+// primitives ("cluster") gets a bounding ball.  The culling kernels test clusters first.  Reordering is
+// invisible in the results: hits are reported by object number, and the closest-hit rule
+// (t, object number) lexicographic minimum does not depend on the visiting order.
+static inline uint32_t spread10(uint32_t v)
+{
+  v &= 0x3ff;
+  v = (v | (v << 16)) & 0x030000ff;
+  v = (v | (v << 8)) & 0x0300f00f;
+  v = (v | (v << 4)) & 0x030c30c3;
+  v = (v | (v << 2)) & 0x09249249;
+  return v;
+}
+
+// order[i] = index of the primitive stored at position i; bound(i, out4) gives centre + radius
+template <class BoundFn> static void morton_order(size_t n, BoundFn bound, std::vector<uint32_t> &order)
+{
+  order.resize(n);
+  for (size_t i = 0; i < n; ++i) order[i] = (uint32_t)i;
+  if (n <= 64) return; // one cluster: order is irrelevant
+  double lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+  std::vector<float> c(4 * n);
+  for (size_t i = 0; i < n; ++i) {
+    bound(i, &c[4 * i]);
+    if (!std::isfinite(c[4 * i + 3])) continue;
+    for (int a = 0; a < 3; ++a) { lo[a] = std::fmin(lo[a], c[4 * i + a]); hi[a] = std::fmax(hi[a], c[4 * i + a]); }
+  }
+  std::vector<uint64_t> key(n);
+  for (size_t i = 0; i < n; ++i) {
+    const float *b = &c[4 * i];
+    if (!std::isfinite(b[3]) || !std::isfinite(b[0]) || !std::isfinite(b[1]) || !std::isfinite(b[2])) {
+      key[i] = (uint64_t)1 << 40; // unbounded primitives go last, into clusters of their own kind
+      continue;
+    }
+    uint32_t q[3];
+    for (int a = 0; a < 3; ++a) {
+      const double span = hi[a] - lo[a];
+      const double f = span > 0 ? (b[a] - lo[a]) / span : 0.0;
+      q[a] = (uint32_t)std::fmin(1023.0, std::fmax(0.0, f * 1023.0));
+    }
+    key[i] = spread10(q[0]) | (spread10(q[1]) << 1) | (spread10(q[2]) << 2);
+  }
+  std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return key[a] < key[b]; });
+}
+
+// bounding ball of each run of 64 balls (streams x,y,z,r of n floats) -> 4 streams of ceil(n/64) floats
+static void cluster_bounds(const float *x, const float *y, const float *z, const float *r, size_t n, float *out)
+{
+  const size_t nc = (n + 63) / 64;
+  for (size_t c = 0; c < nc; ++c) {
+    const size_t b = c * 64, e = std::min(n, b + 64);
+    double lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    bool finite = true;
+    for (size_t i = b; i < e; ++i) {
+      const double p[3] = {x[i], y[i], z[i]}, rr = r[i];
+      if (!std::isfinite(rr) || !std::isfinite(p[0]) || !std::isfinite(p[1]) || !std::isfinite(p[2])) { finite = false; break; }
+      for (int a = 0; a < 3; ++a) { lo[a] = std::fmin(lo[a], p[a] - rr); hi[a] = std::fmax(hi[a], p[a] + rr); }
+    }
+    float o[4] = {0.0f, 0.0f, 0.0f, INFINITY};
+    if (finite) {
+      const double m[3] = {0.5 * (lo[0] + hi[0]), 0.5 * (lo[1] + hi[1]), 0.5 * (lo[2] + hi[2])};
+      const float mf[3] = {(float)m[0], (float)m[1], (float)m[2]};
+      double R = 0.0;
+      for (size_t i = b; i < e; ++i) {
+        const double d[3] = {x[i] - (double)mf[0], y[i] - (double)mf[1], z[i] - (double)mf[2]};
+        R = std::fmax(R, std::sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]) + (double)r[i]);
+      }
+      R *= 1.000001;
+      if (std::isfinite(R) && R < 1e30) { o[0] = mf[0]; o[1] = mf[1]; o[2] = mf[2]; o[3] = std::nextafter((float)R, INFINITY); }
+    }
+    for (int k = 0; k < 4; ++k) out[k * nc + c] = o[k];
   }
 }
 
@@ -239,7 +315,7 @@ int mrt_scene_upload(mrt_ctx *ctx, const mrt_scene_desc *s)
     return fail(ctx, MRT_ERR_INVALID, "missing light arrays");
   if ((int64_t)s->num_spheres + s->num_triangles > s->num_objects)
     return fail(ctx, MRT_ERR_INVALID, "more primitives than objects");
-  // object numbers: in range, strictly ascending per type (closest-hit tie rule relies on it)
+  // object numbers: in range, strictly ascending per type (a scene lists every object once)
   for (int t = 0; t < 2; ++t) {
     const int32_t *o = t ? s->tri_obj : s->sphere_obj;
     const int n = t ? s->num_triangles : s->num_spheres;
@@ -259,6 +335,8 @@ int mrt_scene_upload(mrt_ctx *ctx, const mrt_scene_desc *s)
   auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
   const size_t o_cx = take(ns * 4), o_cy = take(ns * 4), o_cz = take(ns * 4), o_r = take(ns * 4), o_so = take(ns * 4);
   const size_t o_tri = take(nt * 16 * 4), o_to = take(nt * 4), o_tb = take(nt * 4 * 4), o_trec = take(nt * 64);
+  const size_t ncs = (ns + 63) / 64, nct = (nt + 63) / 64;
+  const size_t o_cs = take(ncs * 16), o_ct = take(nct * 16);
   const size_t o_mk = take(no), o_mrgb = take(no * 12);
   const size_t o_lk = take(nl), o_lv = take(nl * 12), o_lc = take(nl * 12);
   const size_t total = off ? off : 256;
@@ -266,15 +344,43 @@ int mrt_scene_upload(mrt_ctx *ctx, const mrt_scene_desc *s)
   std::vector<unsigned char> img;
   try { img.assign(total, 0); } catch (...) { return fail(ctx, MRT_ERR_INVALID, "out of host memory"); }
   auto put = [&](size_t o, const void *src, size_t bytes) { if (bytes) std::memcpy(img.data() + o, src, bytes); };
-  put(o_cx, s->sphere_cx, ns * 4); put(o_cy, s->sphere_cy, ns * 4); put(o_cz, s->sphere_cz, ns * 4);
-  put(o_r, s->sphere_r, ns * 4);   put(o_so, s->sphere_obj, ns * 4);
-  put(o_tri, s->tri, nt * 64);     put(o_to, s->tri_obj, nt * 4);
-  for (size_t i = 0; i < nt; ++i) {
-    float q[16], b[4];
-    for (int k = 0; k < 16; ++k) q[k] = s->tri[k * nt + i];
-    tri_bound(q, b);
-    for (int k = 0; k < 4; ++k) ((float *)(img.data() + o_tb))[k * nt + i] = b[k];
-    std::memcpy(img.data() + o_trec + 64 * i, q, 64);
+  {
+    // spheres, in Morton order
+    std::vector<uint32_t> order;
+    morton_order(ns, [&](size_t i, float *b) { b[0] = s->sphere_cx[i]; b[1] = s->sphere_cy[i]; b[2] = s->sphere_cz[i];
+                                               b[3] = s->sphere_r[i]; }, order);
+    float *cx = (float *)(img.data() + o_cx), *cy = (float *)(img.data() + o_cy), *cz = (float *)(img.data() + o_cz);
+    float *r = (float *)(img.data() + o_r);
+    int32_t *so = (int32_t *)(img.data() + o_so);
+    for (size_t i = 0; i < ns; ++i) {
+      const uint32_t g = order[i];
+      cx[i] = s->sphere_cx[g]; cy[i] = s->sphere_cy[g]; cz[i] = s->sphere_cz[g]; r[i] = s->sphere_r[g];
+      so[i] = s->sphere_obj[g];
+    }
+    // a sphere's own ball must contain it even for a negative radius: the hit test only sees r*r
+    std::vector<float> rabs(ns);
+    for (size_t i = 0; i < ns; ++i) rabs[i] = std::fabs(r[i]);
+    cluster_bounds(cx, cy, cz, rabs.data(), ns, (float *)(img.data() + o_cs));
+  }
+  {
+    // triangles: bounds of the accepted regions first, then Morton order of those
+    std::vector<float> tb(4 * nt);
+    for (size_t i = 0; i < nt; ++i) {
+      float q[16];
+      for (int k = 0; k < 16; ++k) q[k] = s->tri[k * nt + i];
+      tri_bound(q, &tb[4 * i]);
+    }
+    std::vector<uint32_t> order;
+    morton_order(nt, [&](size_t i, float *b) { std::memcpy(b, &tb[4 * i], 16); }, order);
+    float *tri = (float *)(img.data() + o_tri), *bnd = (float *)(img.data() + o_tb), *rec = (float *)(img.data() + o_trec);
+    int32_t *to = (int32_t *)(img.data() + o_to);
+    for (size_t i = 0; i < nt; ++i) {
+      const uint32_t g = order[i];
+      for (int k = 0; k < 16; ++k) { const float v = s->tri[k * nt + g]; tri[k * nt + i] = v; rec[16 * i + k] = v; }
+      for (int k = 0; k < 4; ++k) bnd[k * nt + i] = tb[4 * g + k];
+      to[i] = s->tri_obj[g];
+    }
+    cluster_bounds(bnd, bnd + nt, bnd + 2 * nt, bnd + 3 * nt, nt, (float *)(img.data() + o_ct));
   }
   put(o_mk, s->mat_kind, no);      put(o_mrgb, s->mat_rgb, no * 12);
   put(o_lk, s->light_kind, nl);    put(o_lv, s->light_vec, nl * 12); put(o_lc, s->light_rgb, nl * 12);
@@ -296,6 +402,8 @@ int mrt_scene_upload(mrt_ctx *ctx, const mrt_scene_desc *s)
   d.tri = (const float *)(b + o_tri);   d.tri_obj = (const int32_t *)(b + o_to); d.nt = (int32_t)nt;
   d.tri_bx = (const float *)(b + o_tb); d.tri_by = d.tri_bx + nt; d.tri_bz = d.tri_bx + 2 * nt; d.tri_br = d.tri_bx + 3 * nt;
   d.tri_rec = (const float *)(b + o_trec);
+  d.sph_clu = (const float *)(b + o_cs); d.ncs = (int32_t)ncs;
+  d.tri_clu = (const float *)(b + o_ct); d.nct = (int32_t)nct;
   d.mat_kind = b + o_mk; d.mat_rgb = (const float *)(b + o_mrgb); d.nobj = (int32_t)no;
   d.light_kind = b + o_lk; d.light_vec = (const float *)(b + o_lv); d.light_rgb = (const float *)(b + o_lc);
   d.nl = (int32_t)nl;

@@ -29,6 +29,27 @@
 
 namespace mrt {
 
+// Cluster level: lanes test 64 cluster balls (streams x,y,z,r of nc floats at clu) with `test(x,y,z,r)`;
+// returns the wave-uniform mask of clusters cb..cb+63 that may be touched.  A type with a single cluster
+// skips the test (tiny scenes: C2).
+template <class Test>
+__device__ __forceinline__ unsigned long long cluster_mask(const float *__restrict__ clu, int nc, int cb, int lane,
+                                                           Test test)
+{
+  if (nc == 1) return 1ull;
+  const int ci = cb + lane;
+  bool pass = false;
+  if (ci < nc) pass = test(clu[ci], clu[nc + ci], clu[2 * nc + ci], clu[3 * nc + ci]);
+  return __ballot(pass);
+}
+
+// effective radius of a cluster ball of radius R whose members are seen from distance <= Lmax:
+// a member sphere's cull radius is sqrt(r^2 + s L^2) <= r + sqrt(s) L, sqrt(CULL_DISC_SLACK) = 2e-3
+__device__ __forceinline__ float cluster_cull_radius(float R, float Lmax)
+{
+  return R * CULL_REL + 2.0e-3f * CULL_REL * Lmax + CULL_ABS;
+}
+
 __global__ __launch_bounds__(256) void render_cull_kernel(RenderArgs A)
 {
   const DevScene &sc = A.sc;
@@ -98,7 +119,15 @@ __global__ __launch_bounds__(256) void render_cull_kernel(RenderArgs A)
     int best_obj = 0x7fffffff, best_prim = -1;
 
     // ---- closest hit over spheres: src/main.cu:60-77, core/sphere.cuh:32-73, interval [0.01, inf] ----
-    for (int base = 0; base < ns; base += 64) {
+    for (int cb = 0; cb < sc.ncs; cb += 64) {
+     unsigned long long cmask = cluster_mask(sc.sph_clu, sc.ncs, cb, lane, [&](float x, float y, float z, float R) {
+       const float wx = x - cam.ox, wy = y - cam.oy, wz = z - cam.oz;
+       const float L = fast_sqrt(dot3(wx, wy, wz, wx, wy, wz)) * CULL_REL + R;
+       return ball_may_touch_cone(wx, wy, wz, cluster_cull_radius(R, L), cax, cay, caz, cosT, sinT);
+     });
+     while (cmask) {
+      const int base = (cb + __builtin_ctzll(cmask)) * 64;
+      cmask &= cmask - 1;
       const int i = base + lane;
       float cx = 0.0f, cy = 0.0f, cz = 0.0f, r = 0.0f;
       bool pass = false;
@@ -127,10 +156,17 @@ __global__ __launch_bounds__(256) void render_cull_kernel(RenderArgs A)
           }
         }
       }
+     }
     }
 
     // ---- closest hit over triangles: core/triangle.cuh:77-103 ----
-    for (int base = 0; base < nt; base += 64) {
+    for (int cb = 0; cb < sc.nct; cb += 64) {
+     unsigned long long cmask = cluster_mask(sc.tri_clu, sc.nct, cb, lane, [&](float x, float y, float z, float R) {
+       return ball_may_touch_cone(x - cam.ox, y - cam.oy, z - cam.oz, R * CULL_REL + CULL_ABS, cax, cay, caz, cosT, sinT);
+     });
+     while (cmask) {
+      const int base = (cb + __builtin_ctzll(cmask)) * 64;
+      cmask &= cmask - 1;
       const int i = base + lane;
       bool pass = false;
       if (i < nt) {
@@ -157,6 +193,7 @@ __global__ __launch_bounds__(256) void render_cull_kernel(RenderArgs A)
           }
         }
       }
+     }
     }
 
     // ---- hit record of the winner (core/sphere.cuh:45-47, core/triangle.cuh:96-97) ----
@@ -225,7 +262,15 @@ __global__ __launch_bounds__(256) void render_cull_kernel(RenderArgs A)
         bool wave_open = __any(open);
 
         // any-hit over spheres, interval [1e-3, t_light] (core/light.cuh:28-33)
-        for (int base = 0; base < ns && wave_open; base += 64) {
+        for (int cb = 0; cb < sc.ncs && wave_open; cb += 64) {
+         unsigned long long cmask = cluster_mask(sc.sph_clu, sc.ncs, cb, lane, [&](float x, float y, float z, float R) {
+           const float wx = x - B.mx, wy = y - B.my, wz = z - B.mz;
+           const float Lm = fast_sqrt(dot3(wx, wy, wz, wx, wy, wz)) * CULL_REL + B.rho + R;
+           return bundle_may_touch(B, x, y, z, cluster_cull_radius(R, Lm));
+         });
+         while (cmask && wave_open) {
+          const int base = (cb + __builtin_ctzll(cmask)) * 64;
+          cmask &= cmask - 1;
           const int i = base + lane;
           float cx = 0.0f, cy = 0.0f, cz = 0.0f, r = 0.0f;
           bool pass = false;
@@ -250,9 +295,16 @@ __global__ __launch_bounds__(256) void render_cull_kernel(RenderArgs A)
             }
             if (!__any(open)) { wave_open = false; break; } // ballot early-out
           }
+         }
         }
         // any-hit over triangles
-        for (int base = 0; base < nt && wave_open; base += 64) {
+        for (int cb = 0; cb < sc.nct && wave_open; cb += 64) {
+         unsigned long long cmask = cluster_mask(sc.tri_clu, sc.nct, cb, lane, [&](float x, float y, float z, float R) {
+           return bundle_may_touch(B, x, y, z, R);
+         });
+         while (cmask && wave_open) {
+          const int base = (cb + __builtin_ctzll(cmask)) * 64;
+          cmask &= cmask - 1;
           const int i = base + lane;
           bool pass = false;
           if (i < nt) pass = bundle_may_touch(B, sc.tri_bx[i], sc.tri_by[i], sc.tri_bz[i], sc.tri_br[i]);
@@ -272,6 +324,7 @@ __global__ __launch_bounds__(256) void render_cull_kernel(RenderArgs A)
             if (open && h) open = false;
             if (!__any(open)) { wave_open = false; break; }
           }
+         }
         }
 
         if (need && valid) { n_shadow++; if (!open) n_occl++; }

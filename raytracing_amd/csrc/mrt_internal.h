@@ -6,7 +6,8 @@
 
 namespace mrt {
 
-// Scene as it lives in HBM: pure SoA streams, one allocation per group.
+// Scene as it lives in HBM: pure SoA streams, one allocation.  Primitives of a type are stored in Morton
+// order of their bound centres (mrt_api.cpp); *_obj carries the object number every result is reported in.
 struct DevScene {
   // spheres: 4 streams of ns floats (core/sphere.cuh:116-117) + object numbers
   const float *sph_cx, *sph_cy, *sph_cz, *sph_r;
@@ -21,6 +22,10 @@ struct DevScene {
   // the same 16 floats per triangle, contiguous (64 B records), for wave-uniform fetches of the few
   // triangles that survive culling (one s_load_dwordx16 instead of 16 strided scalar loads)
   const float *tri_rec;
+  // bounding balls of runs of 64 consecutive primitives (primitives are stored in Morton order):
+  // 4 streams (x, y, z, r) of ncs / nct floats each
+  const float *sph_clu, *tri_clu;
+  int32_t ncs, nct;
   int32_t nt;
   // per object material (core/material.cuh:78,160)
   const uint8_t *mat_kind;
