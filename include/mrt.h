@@ -129,6 +129,12 @@ const char *mrt_status_string(int status);
 enum { MRT_OPT_CULL = 1 };
 int mrt_ctx_set_option(mrt_ctx *ctx, int option, int value);
 
+/*
+ * Host-only diagnostic (no GPU, no context): the conservative bounding ball (centre xyz, radius) the culling
+ * kernels use for one triangle given in the 16-float precomputed form.  Radius +inf = never culled.
+ */
+int mrt_triangle_bound(const float tri16[16], float out4[4]);
+
 /* --- scene: replaces cudaMallocManaged-backed rt::Vector (container/vector.cuh:26,131) */
 int mrt_scene_upload(mrt_ctx *ctx, const mrt_scene_desc *scene);
 

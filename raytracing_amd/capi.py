@@ -19,7 +19,7 @@ LIGHT_DIRECTIONAL, LIGHT_POINT = 0, 1
 # every symbol include/mrt.h declares (tests check the library exports all of them)
 MRT_SYMBOLS = [
     "mrt_device_count", "mrt_ctx_create", "mrt_ctx_destroy", "mrt_ctx_set_option", "mrt_last_error", "mrt_status_string",
-    "mrt_scene_upload", "mrt_local_rows", "mrt_render", "mrt_render_device", "mrt_assemble_strips",
+    "mrt_triangle_bound", "mrt_scene_upload", "mrt_local_rows", "mrt_render", "mrt_render_device", "mrt_assemble_strips",
     "mrt_intersect",
 ]
 
@@ -96,6 +96,7 @@ def libmrt():
         L.mrt_status_string.argtypes = [C.c_int]
         L.mrt_status_string.restype = C.c_char_p
         L.mrt_scene_upload.argtypes = [C.c_void_p, C.POINTER(SceneDesc)]
+        L.mrt_triangle_bound.argtypes = [_f, _f]
         L.mrt_local_rows.argtypes = [C.c_int32, C.POINTER(Partition), _i32]
         L.mrt_render.argtypes = [C.c_void_p, C.POINTER(Camera), C.POINTER(RenderParams), C.c_void_p, C.c_void_p,
                                  C.c_void_p, C.POINTER(Stats)]
@@ -152,6 +153,16 @@ def triangle_precompute(verts):
     out = np.zeros((16, n), dtype=np.float32)
     if n:
         libhost().rth_triangle_precompute(_fp(v), n, _fp(out))
+    return out
+
+
+def triangle_bound(tri16):
+    """Bounding ball (x, y, z, r) the culling kernels use for a precomputed triangle (host-only diagnostic)."""
+    q = np.ascontiguousarray(tri16, dtype=np.float32).reshape(16)
+    out = np.zeros(4, dtype=np.float32)
+    rc = libmrt().mrt_triangle_bound(_fp(q), _fp(out))
+    if rc != 0:
+        raise MrtError(f"mrt_triangle_bound: {rc}")
     return out
 
 

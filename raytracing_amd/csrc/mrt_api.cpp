@@ -113,6 +113,7 @@ template <class BoundFn> static void morton_order(size_t n, BoundFn bound, std::
     if (!std::isfinite(c[4 * i + 3])) continue;
     for (int a = 0; a < 3; ++a) { lo[a] = std::fmin(lo[a], c[4 * i + a]); hi[a] = std::fmax(hi[a], c[4 * i + a]); }
   }
+  const double span = std::fmax(hi[0] - lo[0], std::fmax(hi[1] - lo[1], hi[2] - lo[2]));
   std::vector<uint64_t> key(n);
   for (size_t i = 0; i < n; ++i) {
     const float *b = &c[4 * i];
@@ -120,9 +121,9 @@ template <class BoundFn> static void morton_order(size_t n, BoundFn bound, std::
       key[i] = (uint64_t)1 << 40; // unbounded primitives go last, into clusters of their own kind
       continue;
     }
+    // one scale for the three axes (the largest extent): a thin axis must not contribute high Morton bits
     uint32_t q[3];
     for (int a = 0; a < 3; ++a) {
-      const double span = hi[a] - lo[a];
       const double f = span > 0 ? (b[a] - lo[a]) / span : 0.0;
       q[a] = (uint32_t)std::fmin(1023.0, std::fmax(0.0, f * 1023.0));
     }
@@ -302,6 +303,13 @@ static void tri_bound(const float q[16], float out[4])
   out[3] = std::nextafter((float)rad, INFINITY);
 }
 
+int mrt_triangle_bound(const float tri16[16], float out4[4])
+{
+  if (!tri16 || !out4) return MRT_ERR_INVALID;
+  tri_bound(tri16, out4);
+  return MRT_OK;
+}
+
 int mrt_scene_upload(mrt_ctx *ctx, const mrt_scene_desc *s)
 {
   if (!ctx || !s) return MRT_ERR_INVALID;
@@ -337,6 +345,8 @@ int mrt_scene_upload(mrt_ctx *ctx, const mrt_scene_desc *s)
   const size_t o_tri = take(nt * 16 * 4), o_to = take(nt * 4), o_tb = take(nt * 4 * 4), o_trec = take(nt * 64);
   const size_t ncs = (ns + 63) / 64, nct = (nt + 63) / 64;
   const size_t o_cs = take(ncs * 16), o_ct = take(nct * 16);
+  const size_t nscs = (ncs + 63) / 64, nsct = (nct + 63) / 64;
+  const size_t o_scs = take(nscs * 16), o_sct = take(nsct * 16);
   const size_t o_mk = take(no), o_mrgb = take(no * 12);
   const size_t o_lk = take(nl), o_lv = take(nl * 12), o_lc = take(nl * 12);
   const size_t total = off ? off : 256;
@@ -360,7 +370,9 @@ int mrt_scene_upload(mrt_ctx *ctx, const mrt_scene_desc *s)
     // a sphere's own ball must contain it even for a negative radius: the hit test only sees r*r
     std::vector<float> rabs(ns);
     for (size_t i = 0; i < ns; ++i) rabs[i] = std::fabs(r[i]);
-    cluster_bounds(cx, cy, cz, rabs.data(), ns, (float *)(img.data() + o_cs));
+    float *cs = (float *)(img.data() + o_cs);
+    cluster_bounds(cx, cy, cz, rabs.data(), ns, cs);
+    cluster_bounds(cs, cs + ncs, cs + 2 * ncs, cs + 3 * ncs, ncs, (float *)(img.data() + o_scs));
   }
   {
     // triangles: bounds of the accepted regions first, then Morton order of those
@@ -380,7 +392,9 @@ int mrt_scene_upload(mrt_ctx *ctx, const mrt_scene_desc *s)
       for (int k = 0; k < 4; ++k) bnd[k * nt + i] = tb[4 * g + k];
       to[i] = s->tri_obj[g];
     }
-    cluster_bounds(bnd, bnd + nt, bnd + 2 * nt, bnd + 3 * nt, nt, (float *)(img.data() + o_ct));
+    float *ct = (float *)(img.data() + o_ct);
+    cluster_bounds(bnd, bnd + nt, bnd + 2 * nt, bnd + 3 * nt, nt, ct);
+    cluster_bounds(ct, ct + nct, ct + 2 * nct, ct + 3 * nct, nct, (float *)(img.data() + o_sct));
   }
   put(o_mk, s->mat_kind, no);      put(o_mrgb, s->mat_rgb, no * 12);
   put(o_lk, s->light_kind, nl);    put(o_lv, s->light_vec, nl * 12); put(o_lc, s->light_rgb, nl * 12);
@@ -404,6 +418,8 @@ int mrt_scene_upload(mrt_ctx *ctx, const mrt_scene_desc *s)
   d.tri_rec = (const float *)(b + o_trec);
   d.sph_clu = (const float *)(b + o_cs); d.ncs = (int32_t)ncs;
   d.tri_clu = (const float *)(b + o_ct); d.nct = (int32_t)nct;
+  d.sph_sclu = (const float *)(b + o_scs); d.nscs = (int32_t)nscs;
+  d.tri_sclu = (const float *)(b + o_sct); d.nsct = (int32_t)nsct;
   d.mat_kind = b + o_mk; d.mat_rgb = (const float *)(b + o_mrgb); d.nobj = (int32_t)no;
   d.light_kind = b + o_lk; d.light_vec = (const float *)(b + o_lv); d.light_rgb = (const float *)(b + o_lc);
   d.nl = (int32_t)nl;

@@ -4,8 +4,10 @@
 // results of that loop depend only on the primitives a ray can actually hit, so this kernel first asks,
 // once per 8x8 pixel tile (one wave64), which primitives can be hit by ANY ray of the tile:
 //
-//   * the 64 lanes each take a DIFFERENT primitive (coalesced SoA loads: 64 primitives per instruction)
-//     and test its bounding sphere against a bound of the tile's ray bundle
+//   * primitives are stored in Morton order with bounding balls for every 64 primitives (cluster) and every
+//     64 clusters (super-cluster), built at upload (mrt_api.cpp).  At each level the 64 lanes each take a
+//     DIFFERENT ball (coalesced SoA loads: 64 balls per instruction) and test it against a bound of the
+//     tile's ray bundle
 //       - primary rays:   a circular cone from the camera origin around the tile's four corner rays
 //       - shadow rays:    the swept sphere of the tile's hit points along the light direction
 //                         (directional light) or towards the light position (point light);
@@ -29,21 +31,43 @@
 
 namespace mrt {
 
-// Cluster level: lanes test 64 cluster balls (streams x,y,z,r of nc floats at clu) with `test(x,y,z,r)`;
-// returns the wave-uniform mask of clusters cb..cb+63 that may be touched.  A type with a single cluster
-// skips the test (tiny scenes: C2).
+// ---- primitive-side hierarchy walk ---------------------------------------------------------------------
+// Primitives are stored in Morton order; runs of 64 primitives have a bounding ball ("cluster"), runs of 64
+// clusters another one ("super-cluster").  A wave walks the hierarchy with lane-parallel tests at every
+// level: 64 super-clusters per step, then the 64 clusters of each surviving super-cluster, then
+// body(first primitive of the cluster) for each surviving cluster.  A level with a single entry is not
+// tested (tiny scenes: C2).  body returns false to stop the walk (shadow early-out).
 template <class Test>
-__device__ __forceinline__ unsigned long long cluster_mask(const float *__restrict__ clu, int nc, int cb, int lane,
-                                                           Test test)
+__device__ __forceinline__ unsigned long long level_mask(const float *__restrict__ balls, int n, int begin, int lane,
+                                                         Test test)
 {
-  if (nc == 1) return 1ull;
-  const int ci = cb + lane;
+  if (n == 1) return 1ull;
+  const int i = begin + lane;
   bool pass = false;
-  if (ci < nc) pass = test(clu[ci], clu[nc + ci], clu[2 * nc + ci], clu[3 * nc + ci]);
+  if (i < min(n, begin + 64)) pass = test(balls[i], balls[n + i], balls[2 * n + i], balls[3 * n + i]);
   return __ballot(pass);
 }
 
-// effective radius of a cluster ball of radius R whose members are seen from distance <= Lmax:
+template <class Test, class Body>
+__device__ __forceinline__ void walk_hierarchy(const float *__restrict__ sclu, int nsc, const float *__restrict__ clu,
+                                               int nc, int lane, Test test, Body body)
+{
+  for (int sb = 0; sb < nsc; sb += 64) {
+    unsigned long long smask = level_mask(sclu, nsc, sb, lane, test);
+    while (smask) {
+      const int cb = (sb + __builtin_ctzll(smask)) * 64;
+      smask &= smask - 1;
+      unsigned long long cmask = level_mask(clu, nc, cb, lane, test);
+      while (cmask) {
+        const int base = (cb + __builtin_ctzll(cmask)) * 64;
+        cmask &= cmask - 1;
+        if (!body(base)) return;
+      }
+    }
+  }
+}
+
+// effective radius of a ball of radius R containing spheres seen from distance <= Lmax:
 // a member sphere's cull radius is sqrt(r^2 + s L^2) <= r + sqrt(s) L, sqrt(CULL_DISC_SLACK) = 2e-3
 __device__ __forceinline__ float cluster_cull_radius(float R, float Lmax)
 {
@@ -73,11 +97,10 @@ __global__ __launch_bounds__(256) void render_cull_kernel(RenderArgs A)
   const int grow = grow0 + ty;
   const bool valid = (lrow < A.local_rows) && (grow < A.H) && (col < A.W);
 
-  // ---- cone around the tile's rays.  Corners one pixel outside the tile, which also covers the
-  //      sub-pixel offsets of the 121-spp pattern (within (-11/13, +9/13) pixel) ----
-  // d(u,v) is affine in (u,v), so every ray of the (padded) tile is the centre ray plus an offset of norm
-  // <= cone_ext (half a padded tile in u and v, computed by the launcher): the angle to the centre ray is
-  // at most asin(cone_ext / |centre ray|).
+  // ---- cone around the tile's rays, padded by one pixel on every side (which also covers the sub-pixel
+  //      offsets of the 121-spp pattern, within (-11/13, +9/13) pixel).  d(u,v) is affine in (u,v), so every
+  //      ray of the padded tile is the centre ray plus an offset of norm <= cone_ext (launcher): the angle
+  //      to the centre ray is at most asin(cone_ext / |centre ray|). ----
   float cax, cay, caz, cosT, sinT;
   {
     const float rw = fast_rcp(float(A.W)), rh = fast_rcp(float(A.H)); // bound arithmetic: approximate is fine
@@ -92,6 +115,15 @@ __global__ __launch_bounds__(256) void render_cull_kernel(RenderArgs A)
     // a cone of 90 degrees or more (or a NaN camera) cannot cull: cos = -1 makes every ball pass
     if (!(sinT < 0.99f) || !(cosT > 0.0f)) { cosT = -1.0f; sinT = 0.0f; }
   }
+  // hierarchy tests against the cone: a ball of spheres / a ball of triangle bounds
+  auto cone_vs_sphere_ball = [&](float x, float y, float z, float R) {
+    const float wx = x - cam.ox, wy = y - cam.oy, wz = z - cam.oz;
+    const float L = fast_sqrt(dot3(wx, wy, wz, wx, wy, wz)) * CULL_REL + R;
+    return ball_may_touch_cone(wx, wy, wz, cluster_cull_radius(R, L), cax, cay, caz, cosT, sinT);
+  };
+  auto cone_vs_tri_ball = [&](float x, float y, float z, float R) {
+    return ball_may_touch_cone(x - cam.ox, y - cam.oy, z - cam.oz, R * CULL_REL + CULL_ABS, cax, cay, caz, cosT, sinT);
+  };
 
   float accr = 0.0f, accg = 0.0f, accb = 0.0f;
   int out_id = -1;
@@ -119,15 +151,7 @@ __global__ __launch_bounds__(256) void render_cull_kernel(RenderArgs A)
     int best_obj = 0x7fffffff, best_prim = -1;
 
     // ---- closest hit over spheres: src/main.cu:60-77, core/sphere.cuh:32-73, interval [0.01, inf] ----
-    for (int cb = 0; cb < sc.ncs; cb += 64) {
-     unsigned long long cmask = cluster_mask(sc.sph_clu, sc.ncs, cb, lane, [&](float x, float y, float z, float R) {
-       const float wx = x - cam.ox, wy = y - cam.oy, wz = z - cam.oz;
-       const float L = fast_sqrt(dot3(wx, wy, wz, wx, wy, wz)) * CULL_REL + R;
-       return ball_may_touch_cone(wx, wy, wz, cluster_cull_radius(R, L), cax, cay, caz, cosT, sinT);
-     });
-     while (cmask) {
-      const int base = (cb + __builtin_ctzll(cmask)) * 64;
-      cmask &= cmask - 1;
+    walk_hierarchy(sc.sph_sclu, sc.nscs, sc.sph_clu, sc.ncs, lane, cone_vs_sphere_ball, [&](int base) {
       const int i = base + lane;
       float cx = 0.0f, cy = 0.0f, cz = 0.0f, r = 0.0f;
       bool pass = false;
@@ -156,23 +180,14 @@ __global__ __launch_bounds__(256) void render_cull_kernel(RenderArgs A)
           }
         }
       }
-     }
-    }
+      return true;
+    });
 
     // ---- closest hit over triangles: core/triangle.cuh:77-103 ----
-    for (int cb = 0; cb < sc.nct; cb += 64) {
-     unsigned long long cmask = cluster_mask(sc.tri_clu, sc.nct, cb, lane, [&](float x, float y, float z, float R) {
-       return ball_may_touch_cone(x - cam.ox, y - cam.oy, z - cam.oz, R * CULL_REL + CULL_ABS, cax, cay, caz, cosT, sinT);
-     });
-     while (cmask) {
-      const int base = (cb + __builtin_ctzll(cmask)) * 64;
-      cmask &= cmask - 1;
+    walk_hierarchy(sc.tri_sclu, sc.nsct, sc.tri_clu, sc.nct, lane, cone_vs_tri_ball, [&](int base) {
       const int i = base + lane;
       bool pass = false;
-      if (i < nt) {
-        const float wx = sc.tri_bx[i] - cam.ox, wy = sc.tri_by[i] - cam.oy, wz = sc.tri_bz[i] - cam.oz;
-        pass = ball_may_touch_cone(wx, wy, wz, sc.tri_br[i] * CULL_REL + CULL_ABS, cax, cay, caz, cosT, sinT);
-      }
+      if (i < nt) pass = cone_vs_tri_ball(sc.tri_bx[i], sc.tri_by[i], sc.tri_bz[i], sc.tri_br[i]);
       unsigned long long mask = __ballot(pass);
       while (mask) {
         const int j = __builtin_ctzll(mask);
@@ -193,8 +208,8 @@ __global__ __launch_bounds__(256) void render_cull_kernel(RenderArgs A)
           }
         }
       }
-     }
-    }
+      return true;
+    });
 
     // ---- hit record of the winner (core/sphere.cuh:45-47, core/triangle.cuh:96-97) ----
     const bool have_hit = best_prim >= 0;
@@ -237,6 +252,13 @@ __global__ __launch_bounds__(256) void render_cull_kernel(RenderArgs A)
         const float e2 = have_hit ? dot3(ex, ey, ez, ex, ey, ez) : 0.0f;
         B.rho = fast_sqrt(wave_max(e2)) * CULL_REL + CULL_ABS;
       }
+      auto bundle_vs_sphere_ball = [&](float x, float y, float z, float R) {
+        const float wx = x - B.mx, wy = y - B.my, wz = z - B.mz;
+        const float Lm = fast_sqrt(dot3(wx, wy, wz, wx, wy, wz)) * CULL_REL + B.rho + R;
+        return bundle_may_touch(B, x, y, z, cluster_cull_radius(R, Lm));
+      };
+      auto bundle_vs_tri_ball = [&](float x, float y, float z, float R) { return bundle_may_touch(B, x, y, z, R); };
+
       for (int li = 0; li < sc.nl; ++li) {
         const int lkind = sc.light_kind[li];
         const float lvx = sc.light_vec[3 * li], lvy = sc.light_vec[3 * li + 1], lvz = sc.light_vec[3 * li + 2];
@@ -259,73 +281,60 @@ __global__ __launch_bounds__(256) void render_cull_kernel(RenderArgs A)
         // the light must not shine through the surface, core/light.cuh:148
         const bool need = have_hit && !(dot3(sdx, sdy, sdz, hnx, hny, hnz) < 0);
         bool open = need;
-        bool wave_open = __any(open);
 
         // any-hit over spheres, interval [1e-3, t_light] (core/light.cuh:28-33)
-        for (int cb = 0; cb < sc.ncs && wave_open; cb += 64) {
-         unsigned long long cmask = cluster_mask(sc.sph_clu, sc.ncs, cb, lane, [&](float x, float y, float z, float R) {
-           const float wx = x - B.mx, wy = y - B.my, wz = z - B.mz;
-           const float Lm = fast_sqrt(dot3(wx, wy, wz, wx, wy, wz)) * CULL_REL + B.rho + R;
-           return bundle_may_touch(B, x, y, z, cluster_cull_radius(R, Lm));
-         });
-         while (cmask && wave_open) {
-          const int base = (cb + __builtin_ctzll(cmask)) * 64;
-          cmask &= cmask - 1;
-          const int i = base + lane;
-          float cx = 0.0f, cy = 0.0f, cz = 0.0f, r = 0.0f;
-          bool pass = false;
-          if (i < ns) {
-            cx = sc.sph_cx[i]; cy = sc.sph_cy[i]; cz = sc.sph_cz[i]; r = sc.sph_r[i];
-            const float wx = cx - B.mx, wy = cy - B.my, wz = cz - B.mz;
-            const float Lm = fast_sqrt(dot3(wx, wy, wz, wx, wy, wz)) * CULL_REL + B.rho; // >= |hit point - centre| in the tile
-            pass = bundle_may_touch(B, cx, cy, cz, sphere_cull_radius(r * r, Lm * Lm));
-          }
-          unsigned long long mask = __ballot(pass);
-          while (mask) {
-            const int j = __builtin_ctzll(mask);
-            mask &= mask - 1;
-            const float scx = bcast(cx, j), scy = bcast(cy, j), scz = bcast(cz, j), sr = bcast(r, j);
-            const float ocx = hpx - scx, ocy = hpy - scy, ocz = hpz - scz;
-            const float b = dot3(ocx, ocy, ocz, sdx, sdy, sdz);
-            const float c = dot3(ocx, ocy, ocz, ocx, ocy, ocz) - sr * sr;
-            const float disc = b * b - sa * c;
-            if (open && disc >= 0.0f) {
-              float t;
-              if (sphere_roots(sa, b, disc, 1e-3f, tl, t)) open = false;
+        if (__any(open))
+          walk_hierarchy(sc.sph_sclu, sc.nscs, sc.sph_clu, sc.ncs, lane, bundle_vs_sphere_ball, [&](int base) {
+            const int i = base + lane;
+            float cx = 0.0f, cy = 0.0f, cz = 0.0f, r = 0.0f;
+            bool pass = false;
+            if (i < ns) {
+              cx = sc.sph_cx[i]; cy = sc.sph_cy[i]; cz = sc.sph_cz[i]; r = sc.sph_r[i];
+              const float wx = cx - B.mx, wy = cy - B.my, wz = cz - B.mz;
+              const float Lm = fast_sqrt(dot3(wx, wy, wz, wx, wy, wz)) * CULL_REL + B.rho; // >= |hit point - centre|
+              pass = bundle_may_touch(B, cx, cy, cz, sphere_cull_radius(r * r, Lm * Lm));
             }
-            if (!__any(open)) { wave_open = false; break; } // ballot early-out
-          }
-         }
-        }
+            unsigned long long mask = __ballot(pass);
+            while (mask) {
+              const int j = __builtin_ctzll(mask);
+              mask &= mask - 1;
+              const float scx = bcast(cx, j), scy = bcast(cy, j), scz = bcast(cz, j), sr = bcast(r, j);
+              const float ocx = hpx - scx, ocy = hpy - scy, ocz = hpz - scz;
+              const float b = dot3(ocx, ocy, ocz, sdx, sdy, sdz);
+              const float c = dot3(ocx, ocy, ocz, ocx, ocy, ocz) - sr * sr;
+              const float disc = b * b - sa * c;
+              if (open && disc >= 0.0f) {
+                float t;
+                if (sphere_roots(sa, b, disc, 1e-3f, tl, t)) open = false;
+              }
+              if (!__any(open)) return false; // ballot early-out
+            }
+            return true;
+          });
         // any-hit over triangles
-        for (int cb = 0; cb < sc.nct && wave_open; cb += 64) {
-         unsigned long long cmask = cluster_mask(sc.tri_clu, sc.nct, cb, lane, [&](float x, float y, float z, float R) {
-           return bundle_may_touch(B, x, y, z, R);
-         });
-         while (cmask && wave_open) {
-          const int base = (cb + __builtin_ctzll(cmask)) * 64;
-          cmask &= cmask - 1;
-          const int i = base + lane;
-          bool pass = false;
-          if (i < nt) pass = bundle_may_touch(B, sc.tri_bx[i], sc.tri_by[i], sc.tri_bz[i], sc.tri_br[i]);
-          unsigned long long mask = __ballot(pass);
-          while (mask) {
-            const int j = __builtin_ctzll(mask);
-            mask &= mask - 1;
-            const float *q = sc.tri_rec + 16 * size_t(base + j);
-            const float pnx = q[0], pny = q[1], pnz = q[2], kp = q[3];
-            const float rdn = dot3(sdx, sdy, sdz, pnx, pny, pnz);
-            const float t = (kp - dot3(hpx, hpy, hpz, pnx, pny, pnz)) / rdn;
-            const float px = hpx + t * sdx, py = hpy + t * sdy, pz = hpz + t * sdz;
-            const float e0 = dot3(q[4], q[5], q[6], px, py, pz) - q[7];
-            const float e1 = dot3(q[8], q[9], q[10], px, py, pz) - q[11];
-            const float e2 = dot3(q[12], q[13], q[14], px, py, pz) - q[15];
-            const bool h = (rdn != 0.0f) & (e0 > -1e-6f) & (e1 > -1e-6f) & (e2 > -1e-6f) & (1e-3f <= t) & (t <= tl);
-            if (open && h) open = false;
-            if (!__any(open)) { wave_open = false; break; }
-          }
-         }
-        }
+        if (__any(open))
+          walk_hierarchy(sc.tri_sclu, sc.nsct, sc.tri_clu, sc.nct, lane, bundle_vs_tri_ball, [&](int base) {
+            const int i = base + lane;
+            bool pass = false;
+            if (i < nt) pass = bundle_may_touch(B, sc.tri_bx[i], sc.tri_by[i], sc.tri_bz[i], sc.tri_br[i]);
+            unsigned long long mask = __ballot(pass);
+            while (mask) {
+              const int j = __builtin_ctzll(mask);
+              mask &= mask - 1;
+              const float *q = sc.tri_rec + 16 * size_t(base + j);
+              const float pnx = q[0], pny = q[1], pnz = q[2], kp = q[3];
+              const float rdn = dot3(sdx, sdy, sdz, pnx, pny, pnz);
+              const float t = (kp - dot3(hpx, hpy, hpz, pnx, pny, pnz)) / rdn;
+              const float px = hpx + t * sdx, py = hpy + t * sdy, pz = hpz + t * sdz;
+              const float e0 = dot3(q[4], q[5], q[6], px, py, pz) - q[7];
+              const float e1 = dot3(q[8], q[9], q[10], px, py, pz) - q[11];
+              const float e2 = dot3(q[12], q[13], q[14], px, py, pz) - q[15];
+              const bool h = (rdn != 0.0f) & (e0 > -1e-6f) & (e1 > -1e-6f) & (e2 > -1e-6f) & (1e-3f <= t) & (t <= tl);
+              if (open && h) open = false;
+              if (!__any(open)) return false;
+            }
+            return true;
+          });
 
         if (need && valid) { n_shadow++; if (!open) n_occl++; }
         if (open) {

@@ -26,6 +26,9 @@ struct DevScene {
   // 4 streams (x, y, z, r) of ncs / nct floats each
   const float *sph_clu, *tri_clu;
   int32_t ncs, nct;
+  // ... and of runs of 64 clusters ("super-clusters")
+  const float *sph_sclu, *tri_sclu;
+  int32_t nscs, nsct;
   int32_t nt;
   // per object material (core/material.cuh:78,160)
   const uint8_t *mat_kind;
