@@ -109,6 +109,8 @@ typedef struct mrt_stats {
   uint64_t shadow_rays;  /* lights passing the L.N >= 0 test (core/light.cuh:148) */
   uint64_t hit_pixels;
   uint64_t occluded;
+  uint64_t exact_tests;     /* wave-level exact primitive tests executed (culling kernels; diagnostic) */
+  uint64_t clusters_opened; /* 64-primitive clusters whose members were bound-tested (one-level kernel) */
   float kernel_ms;       /* HIP-event time of the render kernel(s) */
 } mrt_stats;
 
@@ -156,8 +158,8 @@ int mrt_render(mrt_ctx *ctx, const mrt_camera *cam, const mrt_render_params *par
 /*
  * Asynchronous render into DEVICE buffers on a caller-supplied HIP stream
  * (hipStream_t passed as void*; NULL = HIP's default stream, as in HIP itself).  Same layout
- * as mrt_render.  stats_dev, if not NULL, points to 4 device uint64 that receive
- * primary/shadow/hit/occluded counts.  The caller synchronises.
+ * as mrt_render.  stats_dev, if not NULL, points to 8 device uint64 that receive
+ * primary/shadow/hit/occluded counts, exact-test and opened-cluster counts (2 spare).  The caller synchronises.
  */
 int mrt_render_device(mrt_ctx *ctx, const mrt_camera *cam, const mrt_render_params *params, void *rgb_dev,
                       void *id_dev, void *t_dev, void *stats_dev, void *stream);

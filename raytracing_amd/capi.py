@@ -68,11 +68,13 @@ class RenderParams(C.Structure):
 
 class Stats(C.Structure):
     _fields_ = [("primary_rays", C.c_uint64), ("shadow_rays", C.c_uint64), ("hit_pixels", C.c_uint64),
-                ("occluded", C.c_uint64), ("kernel_ms", C.c_float)]
+                ("occluded", C.c_uint64), ("exact_tests", C.c_uint64), ("clusters_opened", C.c_uint64),
+                ("kernel_ms", C.c_float)]
 
     def as_dict(self):
         return {"primary_rays": int(self.primary_rays), "shadow_rays": int(self.shadow_rays),
-                "hit_pixels": int(self.hit_pixels), "occluded": int(self.occluded), "kernel_ms": float(self.kernel_ms)}
+                "hit_pixels": int(self.hit_pixels), "occluded": int(self.occluded), "exact_tests": int(self.exact_tests),
+                "clusters_opened": int(self.clusters_opened), "kernel_ms": float(self.kernel_ms)}
 
 
 _libmrt = None

@@ -220,7 +220,7 @@ int mrt_ctx_create(int device, mrt_ctx **out)
   if ((e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)) != hipSuccess) return bail(e, "hipStreamCreate");
   if ((e = hipEventCreate(&ctx->ev0)) != hipSuccess) return bail(e, "hipEventCreate");
   if ((e = hipEventCreate(&ctx->ev1)) != hipSuccess) return bail(e, "hipEventCreate");
-  if ((e = hipMalloc((void **)&ctx->stats_dev, 4 * sizeof(unsigned long long))) != hipSuccess) return bail(e, "hipMalloc");
+  if ((e = hipMalloc((void **)&ctx->stats_dev, 8 * sizeof(unsigned long long))) != hipSuccess) return bail(e, "hipMalloc");
   *out = ctx;
   return MRT_OK;
 }
@@ -483,7 +483,7 @@ int mrt_render_device(mrt_ctx *ctx, const mrt_camera *cam, const mrt_render_para
   A.stats = (unsigned long long *)stats_dev;
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   hipStream_t st = (hipStream_t)stream; // NULL = HIP's default stream, as everywhere in HIP
-  if (A.stats) HIP_TRY(ctx, hipMemsetAsync(A.stats, 0, 4 * sizeof(unsigned long long), st));
+  if (A.stats) HIP_TRY(ctx, hipMemsetAsync(A.stats, 0, 8 * sizeof(unsigned long long), st));
   HIP_TRY(ctx, launch_by_mode(ctx->cull, A, st));
   return MRT_OK;
 }
@@ -508,7 +508,7 @@ int mrt_render(mrt_ctx *ctx, const mrt_camera *cam, const mrt_render_params *par
   A.id = (int32_t *)((char *)ctx->out_mem + npix * 12);
   A.t = (float *)((char *)ctx->out_mem + npix * 16);
   A.stats = stats ? ctx->stats_dev : nullptr;
-  if (A.stats) HIP_TRY(ctx, hipMemsetAsync(A.stats, 0, 4 * sizeof(unsigned long long), ctx->stream));
+  if (A.stats) HIP_TRY(ctx, hipMemsetAsync(A.stats, 0, 8 * sizeof(unsigned long long), ctx->stream));
   HIP_TRY(ctx, hipEventRecord(ctx->ev0, ctx->stream));
   HIP_TRY(ctx, launch_by_mode(ctx->cull, A, ctx->stream));
   HIP_TRY(ctx, hipEventRecord(ctx->ev1, ctx->stream));
@@ -517,11 +517,12 @@ int mrt_render(mrt_ctx *ctx, const mrt_camera *cam, const mrt_render_params *par
     if (id) HIP_TRY(ctx, hipMemcpyAsync(id, A.id, npix * 4, hipMemcpyDeviceToHost, ctx->stream));
     if (t) HIP_TRY(ctx, hipMemcpyAsync(t, A.t, npix * 4, hipMemcpyDeviceToHost, ctx->stream));
   }
-  unsigned long long h[4] = {0, 0, 0, 0};
+  unsigned long long h[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   if (stats) HIP_TRY(ctx, hipMemcpyAsync(h, ctx->stats_dev, sizeof h, hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   if (stats) {
     stats->primary_rays = h[0]; stats->shadow_rays = h[1]; stats->hit_pixels = h[2]; stats->occluded = h[3];
+    stats->exact_tests = h[4]; stats->clusters_opened = h[5];
     float ms = 0.0f;
     HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
     stats->kernel_ms = ms;

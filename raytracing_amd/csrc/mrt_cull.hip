@@ -68,10 +68,10 @@ __device__ __forceinline__ void walk_hierarchy(const float *__restrict__ sclu, i
 }
 
 // effective radius of a ball of radius R containing spheres seen from distance <= Lmax:
-// a member sphere's cull radius is sqrt(r^2 + s L^2) <= r + sqrt(s) L, sqrt(CULL_DISC_SLACK) = 2e-3
+// a member sphere's cull radius is sqrt(r^2 + s L^2) <= r + sqrt(s) L
 __device__ __forceinline__ float cluster_cull_radius(float R, float Lmax)
 {
-  return R * CULL_REL + 2.0e-3f * CULL_REL * Lmax + CULL_ABS;
+  return R * CULL_REL + CULL_DISC_SLACK_SQRT * CULL_REL * Lmax + CULL_ABS;
 }
 
 __global__ __launch_bounds__(256) void render_cull_kernel(RenderArgs A)
@@ -129,6 +129,7 @@ __global__ __launch_bounds__(256) void render_cull_kernel(RenderArgs A)
   int out_id = -1;
   float out_t = MRT_INF;
   unsigned int n_shadow = 0, n_hit = 0, n_occl = 0;
+  unsigned int n_exact = 0, n_clusters = 0; // wave-uniform diagnostics (lane 0 reports them)
   const int nsamp = A.spp;
   const float DIVW = 13.0f, DIVH = 13.0f;
   const float v = float(grow) / float(A.H); // src/main.cu:137
@@ -162,6 +163,7 @@ __global__ __launch_bounds__(256) void render_cull_kernel(RenderArgs A)
         pass = ball_may_touch_cone(wx, wy, wz, sphere_cull_radius(r * r, L2), cax, cay, caz, cosT, sinT);
       }
       unsigned long long mask = __ballot(pass);
+      n_clusters++; n_exact += __popcll(mask);
       while (mask) {
         const int j = __builtin_ctzll(mask);
         mask &= mask - 1;
@@ -189,6 +191,7 @@ __global__ __launch_bounds__(256) void render_cull_kernel(RenderArgs A)
       bool pass = false;
       if (i < nt) pass = cone_vs_tri_ball(sc.tri_bx[i], sc.tri_by[i], sc.tri_bz[i], sc.tri_br[i]);
       unsigned long long mask = __ballot(pass);
+      n_clusters++; n_exact += __popcll(mask);
       while (mask) {
         const int j = __builtin_ctzll(mask);
         mask &= mask - 1;
@@ -295,6 +298,7 @@ __global__ __launch_bounds__(256) void render_cull_kernel(RenderArgs A)
               pass = bundle_may_touch(B, cx, cy, cz, sphere_cull_radius(r * r, Lm * Lm));
             }
             unsigned long long mask = __ballot(pass);
+            n_clusters++; n_exact += __popcll(mask);
             while (mask) {
               const int j = __builtin_ctzll(mask);
               mask &= mask - 1;
@@ -318,6 +322,7 @@ __global__ __launch_bounds__(256) void render_cull_kernel(RenderArgs A)
             bool pass = false;
             if (i < nt) pass = bundle_may_touch(B, sc.tri_bx[i], sc.tri_by[i], sc.tri_bz[i], sc.tri_br[i]);
             unsigned long long mask = __ballot(pass);
+            n_clusters++; n_exact += __popcll(mask);
             while (mask) {
               const int j = __builtin_ctzll(mask);
               mask &= mask - 1;
@@ -395,6 +400,10 @@ __global__ __launch_bounds__(256) void render_cull_kernel(RenderArgs A)
       unsigned int x = v4[k];
       for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, 64);
       if (lane == 0 && x) atomicAdd(&A.stats[k], (unsigned long long)x);
+    }
+    if (lane == 0) {
+      atomicAdd(&A.stats[4], (unsigned long long)n_exact);
+      atomicAdd(&A.stats[5], (unsigned long long)n_clusters);
     }
   }
 }

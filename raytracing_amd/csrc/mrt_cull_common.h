@@ -7,16 +7,19 @@
 namespace mrt {
 
 // ---- margins ----------------------------------------------------------------------------------------
-// Exact sphere test: disc = b*b - a*c >= 0 in fp32.  With L = |o - c| the rounding error of disc is below
-// 10 eps a L^2 = 6e-7 a L^2, so disc >= 0 implies (true distance ray-centre)^2 <= r^2 + 6e-7 L^2.
-// The cull radius uses 4e-6 L^2 (6x that), then 0.1 % and 1e-6 on top for the cull arithmetic itself.
-#define CULL_DISC_SLACK 4e-6f
+// Exact sphere test: disc = b*b - a*c >= 0 in fp32.  With L = |o - c| and u = 2^-24, standard forward error
+// analysis of the reference's expression order gives |fl(disc) - disc| <= 16 u a L^2 = 9.5e-7 a L^2, so
+// fl(disc) >= 0 implies (true distance ray-centre)^2 <= r^2 + 9.5e-7 L^2.  The cull radius uses 2e-6 L^2,
+// then 0.1 % and 1e-6 on top for the arithmetic of the bound tests themselves.
+#define CULL_DISC_SLACK 2e-6f
+#define CULL_DISC_SLACK_SQRT 1.5e-3f /* >= sqrt(CULL_DISC_SLACK) */
 #define CULL_REL 1.001f
 #define CULL_ABS 1e-6f
-// cancellation in |w|^2 - proj^2 and the ~1e-6 relative error of the approximate (v_rsq/v_sqrt/v_rcp)
-// arithmetic the bound tests use: lower bound of the perpendicular distance.  The bound tests never
-// need exact arithmetic -- only the exact tests behind them do.
-#define CULL_PERP_SLACK 1e-5f
+// The bound tests use single-instruction approximations (v_rsq/v_sqrt/v_rcp, 1 ulp) and plain fp32; their
+// distances are computed from explicit perpendicular vectors (no cancelling differences of squares), so
+// they are off by at most a few 1e-7 of the lengths involved.  Every comparison gets 4e-6 of the 1-norm
+// of those lengths as slack.  Only the exact tests behind the bounds need exact arithmetic.
+#define CULL_LEN_SLACK 4e-6f
 
 __device__ __forceinline__ float wave_max(float x)
 {
@@ -50,27 +53,28 @@ __device__ __forceinline__ float sphere_cull_radius(float rr, float Lmax2)
   return fast_sqrt(rr + CULL_DISC_SLACK * Lmax2) * CULL_REL + CULL_ABS;
 }
 
-// Cone {x : angle(x - apex, axis) <= theta}: true when the ball (w = centre - apex, radius reff) may
-// touch it.  dist(ball centre, cone) >= perp*cos - proj*sin (distance to the supporting half-space).
+__device__ __forceinline__ float norm1(float x, float y, float z) { return fabsf(x) + fabsf(y) + fabsf(z); }
+
+// Cone {x : angle(x - apex, axis) <= theta}, |axis| = 1: true when the ball (w = centre - apex, radius reff)
+// may touch it.  dist(ball centre, cone) >= perp*cos - proj*sin (distance to the supporting half-space).
 __device__ __forceinline__ bool ball_may_touch_cone(float wx, float wy, float wz, float reff, float ax, float ay,
                                                     float az, float cosT, float sinT)
 {
-  const float L2 = dot3(wx, wy, wz, wx, wy, wz);
   const float proj = dot3(wx, wy, wz, ax, ay, az);
-  const float perp = fast_sqrt(fmaxf(L2 - proj * proj - CULL_PERP_SLACK * L2, 0.0f));
-  return !(perp * cosT - proj * sinT > reff);
+  const float qx = wx - proj * ax, qy = wy - proj * ay, qz = wz - proj * az;
+  const float perp = fast_sqrt(dot3(qx, qy, qz, qx, qy, qz));
+  return !(perp * cosT - proj * sinT > reff + CULL_LEN_SLACK * norm1(wx, wy, wz));
 }
 
-// Ray bundle {m + e + t*D : |e| <= rho, t >= 0} (directional light), D ~ unit: true when the ball may touch it
+// Ray bundle {m + e + t*D : |e| <= rho, t >= 0} (directional light): true when the ball at w = centre - m may
+// come within `reach` of the half-line from m along D (DD = D.D)
 __device__ __forceinline__ bool ball_may_touch_sweep(float wx, float wy, float wz, float reach, float Dx, float Dy,
                                                      float Dz, float DD)
 {
-  const float L2 = dot3(wx, wy, wz, wx, wy, wz);
-  const float proj = dot3(wx, wy, wz, Dx, Dy, Dz);
-  // squared distance to the half-line; behind the origin the distance is |w|
-  const float d2 = (proj > 0.0f) ? (L2 - (proj * proj) * fast_rcp(DD)) : L2;
-  const float dist = fast_sqrt(fmaxf(d2 - CULL_PERP_SLACK * L2, 0.0f));
-  return !(dist > reach);
+  const float s = fmaxf(dot3(wx, wy, wz, Dx, Dy, Dz) * fast_rcp(DD), 0.0f); // behind the origin: distance to m
+  const float qx = wx - s * Dx, qy = wy - s * Dy, qz = wz - s * Dz;
+  const float dist = fast_sqrt(dot3(qx, qy, qz, qx, qy, qz));
+  return !(dist > reach + CULL_LEN_SLACK * (norm1(wx, wy, wz) + s * norm1(Dx, Dy, Dz)));
 }
 
 // Segment bundle: every shadow ray of the tile runs from a point within rho of m to the light position
@@ -78,13 +82,11 @@ __device__ __forceinline__ bool ball_may_touch_sweep(float wx, float wy, float w
 __device__ __forceinline__ bool ball_may_touch_segment(float wx, float wy, float wz, float reach, float ex, float ey,
                                                        float ez, float ee)
 {
-  const float L2 = dot3(wx, wy, wz, wx, wy, wz);
   float s = dot3(wx, wy, wz, ex, ey, ez) * fast_rcp(ee); // ee == 0 gives NaN/inf: clamped below, NaN -> pass
   s = fminf(fmaxf(s, 0.0f), 1.0f);
   const float qx = wx - s * ex, qy = wy - s * ey, qz = wz - s * ez;
-  const float d2 = dot3(qx, qy, qz, qx, qy, qz);
-  const float dist = fast_sqrt(fmaxf(d2 - CULL_PERP_SLACK * (L2 + ee), 0.0f));
-  return !(dist > reach);
+  const float dist = fast_sqrt(dot3(qx, qy, qz, qx, qy, qz));
+  return !(dist > reach + CULL_LEN_SLACK * (norm1(wx, wy, wz) + norm1(ex, ey, ez)));
 }
 
 struct Light {

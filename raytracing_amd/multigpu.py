@@ -59,7 +59,7 @@ class FrameRenderer:
         self.rgb = torch.zeros(n * 3, dtype=torch.float32, device=self.dev)
         self.ids = torch.zeros(n, dtype=torch.int32, device=self.dev) if with_ids else None
         self.tt = torch.zeros(n, dtype=torch.float32, device=self.dev) if with_ids else None
-        self.stats = torch.zeros(4, dtype=torch.int64, device=self.dev)
+        self.stats = torch.zeros(8, dtype=torch.int64, device=self.dev)
         self.gathered = None
         self.frame = None
         self._call = None
@@ -98,7 +98,8 @@ class FrameRenderer:
         self.render_local(want_stats=True)
         self.torch.cuda.synchronize(self.dev)
         s = self.stats.cpu().numpy()
-        return {"primary_rays": int(s[0]), "shadow_rays": int(s[1]), "hit_pixels": int(s[2]), "occluded": int(s[3])}
+        return {"primary_rays": int(s[0]), "shadow_rays": int(s[1]), "hit_pixels": int(s[2]), "occluded": int(s[3]),
+                "exact_tests": int(s[4]), "clusters_opened": int(s[5])}
 
     def frame_host(self):
         """Rank 0: the assembled frame as a numpy array [H, W, 3]."""
