@@ -75,7 +75,8 @@ static hipError_t launch_by_mode(int mode, const mrt::RenderArgs &A, hipStream_t
 {
   if (mode == 1) {
     const long n = (long)A.sc.ns + A.sc.nt;
-    mode = n >= 50000 ? 4 : 2; // measured: two levels pay from ~50k primitives
+    (void)n;
+    mode = 2; // measured: with the primitive-side hierarchy the one-level tile kernel wins everywhere
   }
   switch (mode) {
   case 0: return mrt::launch_render(A, st);

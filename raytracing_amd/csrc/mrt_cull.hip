@@ -48,10 +48,14 @@ __device__ __forceinline__ unsigned long long level_mask(const float *__restrict
   return __ballot(pass);
 }
 
-template <class Test, class Body>
+template <bool HIER, class Test, class Body>
 __device__ __forceinline__ void walk_hierarchy(const float *__restrict__ sclu, int nsc, const float *__restrict__ clu,
                                                int nc, int lane, Test test, Body body)
 {
+  if (!HIER) { // at most one cluster per primitive type (C2): nothing to walk
+    if (nc > 0) body(0);
+    return;
+  }
   for (int sb = 0; sb < nsc; sb += 64) {
     unsigned long long smask = level_mask(sclu, nsc, sb, lane, test);
     while (smask) {
@@ -74,6 +78,7 @@ __device__ __forceinline__ float cluster_cull_radius(float R, float Lmax)
   return R * CULL_REL + CULL_DISC_SLACK_SQRT * CULL_REL * Lmax + CULL_ABS;
 }
 
+template <bool HIER>
 __global__ __launch_bounds__(256) void render_cull_kernel(RenderArgs A)
 {
   const DevScene &sc = A.sc;
@@ -152,7 +157,7 @@ __global__ __launch_bounds__(256) void render_cull_kernel(RenderArgs A)
     int best_obj = 0x7fffffff, best_prim = -1;
 
     // ---- closest hit over spheres: src/main.cu:60-77, core/sphere.cuh:32-73, interval [0.01, inf] ----
-    walk_hierarchy(sc.sph_sclu, sc.nscs, sc.sph_clu, sc.ncs, lane, cone_vs_sphere_ball, [&](int base) {
+    walk_hierarchy<HIER>(sc.sph_sclu, sc.nscs, sc.sph_clu, sc.ncs, lane, cone_vs_sphere_ball, [&](int base) {
       const int i = base + lane;
       float cx = 0.0f, cy = 0.0f, cz = 0.0f, r = 0.0f;
       bool pass = false;
@@ -186,7 +191,7 @@ __global__ __launch_bounds__(256) void render_cull_kernel(RenderArgs A)
     });
 
     // ---- closest hit over triangles: core/triangle.cuh:77-103 ----
-    walk_hierarchy(sc.tri_sclu, sc.nsct, sc.tri_clu, sc.nct, lane, cone_vs_tri_ball, [&](int base) {
+    walk_hierarchy<HIER>(sc.tri_sclu, sc.nsct, sc.tri_clu, sc.nct, lane, cone_vs_tri_ball, [&](int base) {
       const int i = base + lane;
       bool pass = false;
       if (i < nt) pass = cone_vs_tri_ball(sc.tri_bx[i], sc.tri_by[i], sc.tri_bz[i], sc.tri_br[i]);
@@ -287,7 +292,7 @@ __global__ __launch_bounds__(256) void render_cull_kernel(RenderArgs A)
 
         // any-hit over spheres, interval [1e-3, t_light] (core/light.cuh:28-33)
         if (__any(open))
-          walk_hierarchy(sc.sph_sclu, sc.nscs, sc.sph_clu, sc.ncs, lane, bundle_vs_sphere_ball, [&](int base) {
+          walk_hierarchy<HIER>(sc.sph_sclu, sc.nscs, sc.sph_clu, sc.ncs, lane, bundle_vs_sphere_ball, [&](int base) {
             const int i = base + lane;
             float cx = 0.0f, cy = 0.0f, cz = 0.0f, r = 0.0f;
             bool pass = false;
@@ -317,7 +322,7 @@ __global__ __launch_bounds__(256) void render_cull_kernel(RenderArgs A)
           });
         // any-hit over triangles
         if (__any(open))
-          walk_hierarchy(sc.tri_sclu, sc.nsct, sc.tri_clu, sc.nct, lane, bundle_vs_tri_ball, [&](int base) {
+          walk_hierarchy<HIER>(sc.tri_sclu, sc.nsct, sc.tri_clu, sc.nct, lane, bundle_vs_tri_ball, [&](int base) {
             const int i = base + lane;
             bool pass = false;
             if (i < nt) pass = bundle_may_touch(B, sc.tri_bx[i], sc.tri_by[i], sc.tri_bz[i], sc.tri_br[i]);
@@ -422,7 +427,9 @@ hipError_t launch_render_cull(const RenderArgs &in, hipStream_t stream)
   }
   const int tiles_x = (A.W + 7) / 8, tiles_y = (A.local_rows + 7) / 8;
   if (tiles_x == 0 || tiles_y == 0) return hipSuccess;
-  hipLaunchKernelGGL(render_cull_kernel, dim3((tiles_x + 3) / 4, tiles_y), dim3(256), 0, stream, A);
+  const dim3 grid((tiles_x + 3) / 4, tiles_y);
+  if (A.sc.ncs > 1 || A.sc.nct > 1) hipLaunchKernelGGL(render_cull_kernel<true>, grid, dim3(256), 0, stream, A);
+  else hipLaunchKernelGGL(render_cull_kernel<false>, grid, dim3(256), 0, stream, A);
   return hipGetLastError();
 }
 
