@@ -72,35 +72,37 @@ def measured_traffic(config, alg_bytes):
         return None
 
 
-def cpu_baseline(name, spec, cam12, W, H, total_rays_full):
-    """Time the CPU oracle (a scalar port of the reference path) on this host: bounded sample."""
+def cpu_baseline(name, spec, flat, cam12, W, H):
+    """Time the CPU oracle (a scalar port of the reference path) on this host: bounded sample of the same
+    workload.  Brute force costs rays x primitives x (1 + lights), so the sample frame is shrunk (same scene,
+    same camera, fewer pixels) until one frame is about 1e9 primitive tests per thread."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import _oracle as O  # test infrastructure, used here only as the reported CPU baseline
 
     scene = O.Scene.default() if spec is None else O.Scene.from_spec(spec)
     threads = min(16, os.cpu_count() or 1)  # the GPU box's CPU share for one GPU is 16
-    if name == "C2":
-        rows, sw, sh = (0, H), W, H
-    else:  # brute force on the CPU is slow: render a reduced frame and scale per ray
-        sw, sh = W // 8, H // 8
-        rows = (0, sh)
+    per_ray = max(1, flat.num_spheres + flat.num_triangles) * (1 + flat.num_lights)
     out = {}
-    for label, nt in (("1thread", 1), ("threads", threads)):
-        budget, frames, t0, rays = (4.0 if nt == 1 else 8.0), 0, time.perf_counter(), 0
+    for label, nt, budget_tests, budget_s in (("1thread", 1, 1.0e9, 6.0), ("threads", threads, 1.0e9 * threads, 10.0)):
+        scale = 1
+        while (W // scale) * (H // scale) * per_ray > budget_tests and min(W, H) // (scale * 2) >= 8:
+            scale *= 2
+        sw, sh = W // scale, H // scale
+        frames, t0, rays = 0, time.perf_counter(), 0
         while True:
-            r = scene.render(cam12, sw, sh, rows=rows, nthreads=nt, want=("rgb", "id", "t"))
+            r = scene.render(cam12, sw, sh, nthreads=nt, want=("rgb", "id", "t"))
             rays += r["stats"]["primary_rays"] + r["stats"]["shadow_rays"]
             frames += 1
             dt = time.perf_counter() - t0
-            if dt >= budget or frames >= 200:
+            if dt >= budget_s or frames >= 200:
                 break
-        out[label] = (rays / dt / 1e6, frames, dt)
+        out[label] = (rays / dt / 1e6, frames, dt, sw, sh)
     v1, vn = out["1thread"], out["threads"]
     return {
-        "value": round(vn[0], 3), "unit": "Mrays/s", "cores": threads, "kind": "port",
-        "sample": f"{vn[1]} frame(s) of the same scene at {sw}x{sh} in {vn[2]:.1f}s on {threads} threads "
-                  f"(rows split statically); single thread: {v1[0]:.3f} Mrays/s over {v1[1]} frame(s)",
-        "value_1thread": round(v1[0], 3),
+        "value": round(vn[0], 4), "unit": "Mrays/s", "cores": threads, "kind": "port",
+        "sample": f"{vn[1]} frame(s) of the same scene and camera at {vn[3]}x{vn[4]} in {vn[2]:.1f}s on {threads} threads "
+                  f"(rows split statically); single thread: {v1[0]:.4f} Mrays/s over {v1[1]} frame(s) at {v1[3]}x{v1[4]}",
+        "value_1thread": round(v1[0], 4),
     }
 
 
@@ -134,6 +136,11 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
 
+    def progress(msg):  # stderr only: stdout carries the one JSON line
+        if rank == 0:
+            print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
+
+    progress(f"building workload {args.config}")
     flat, cam12, W, H, flops_ray, scene_bytes, spec, label = build_workload(args.config)
     heavy = args.config in ("C3", "C4")
     steps = args.steps if args.steps is not None else (3 if args.config == "C4" else (20 if heavy else 500))
@@ -144,6 +151,7 @@ def main():
     fr.ctx.set_cull(0 if args.brute_force else 1)
     bytes_pp = 12 if args.no_ids else BYTES_PER_PIXEL
 
+    progress("scene uploaded; counting rays")
     # rays per frame (deterministic for a scene + camera): counted once, outside the timed region
     mine = fr.count_rays()
     cnt = torch.tensor([mine["primary_rays"], mine["shadow_rays"], fr.local_rows * W], dtype=torch.int64,
@@ -158,6 +166,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    progress(f"{rays_per_frame} rays per frame; warmup {warmup}, steps {steps}")
     for _ in range(warmup):
         fr.step()
     sync()
@@ -209,12 +218,12 @@ def main():
                        "parallelism": f"{world} GPU(s): 8-row strips round-robin, scene replicated" +
                                       ("" if world == 1 else ", RCCL gather to rank 0 + strip assembly"),
                        "outputs": "rgb f32 + id i32 + t f32" if not args.no_ids else "rgb f32",
-                       "kernel": "tile culling + exact tests (automatic choice of 1 or 2 levels)" if fr.ctx.cull else
+                       "kernel": "render_cull_kernel: per-tile conservative culling over the Morton-ordered primitive hierarchy + exact tests" if fr.ctx.cull else
                                  "render_kernel (brute force)"},
             "roofline": {"bound": "hbm", "achieved": round(ach_gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(ach_gbs / HBM_PEAK_GBS, 5),
                          "traffic": measured_traffic(args.config, alg_bytes) if world == 1 else None,
-                         "kernel": "render_cull*_kernel" if fr.ctx.cull else "render_kernel", "kernel_ms": round(kern_ms, 5),
+                         "kernel": "render_cull_kernel" if fr.ctx.cull else "render_kernel", "kernel_ms": round(kern_ms, 5),
                          "algorithmic_bytes_per_launch": alg_bytes},
             "roofline_valu": {"bound": "fp32 vector ALU (no MFMA: no dense contraction)",
                               "achieved": round(ach_tf, 4), "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
@@ -223,7 +232,8 @@ def main():
                               "algorithmic_flops_per_ray": flops_ray, "algorithmic_flops_per_launch": alg_flops},
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args.config, spec, cam12, W, H, rays_per_frame)
+            progress(f"GPU done ({ms_per_step:.4f} ms/step); timing the CPU oracle (bounded sample, ~20 s)")
+            out["cpu_baseline"] = cpu_baseline(args.config, spec, flat, cam12, W, H)
         print(json.dumps(out), flush=True)
 
     fr.close()
