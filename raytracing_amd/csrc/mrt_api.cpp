@@ -35,6 +35,10 @@ struct mrt_ctx {
   size_t out_bytes = 0;
   unsigned long long *stats_dev = nullptr;
   int cull = 1; // MRT_OPT_CULL value
+
+  // u = col / W, v = row / H tables of the small-scene kernel, for the frame size of the last render
+  float *uv_mem = nullptr;
+  int uv_w = 0, uv_h = 0, uv_nu = 0;
 };
 
 static thread_local std::string g_create_err;
@@ -59,30 +63,58 @@ static int hip_fail(mrt_ctx *ctx, hipError_t e, const char *what)
   } while (0)
 
 // Kernel choice (MRT_OPT_CULL / environment MRT_CULL): 0 brute force (every ray x every primitive, like the
-// reference loops), 1 automatic (default), 2 one-level tile culling, 3 / 4 two-level culling with 4 / 8 waves.
+// reference loops), 1 automatic (default), 2 one-level tile culling, 3 / 4 two-level culling with 4 / 8 waves,
+// 5 the small-scene kernel (at most 64 primitives; larger scenes fall back to 2).
 // All of them produce identical buffers (tests compare them).
 static int use_cull()
 {
   static const int v = [] {
     const char *e = getenv("MRT_CULL");
     const int x = e ? atoi(e) : 1;
-    return (x < 0 || x > 4) ? 1 : x;
+    return (x < 0 || x > 5) ? 1 : x;
   }();
   return v;
 }
 
-static hipError_t launch_by_mode(int mode, const mrt::RenderArgs &A, hipStream_t st)
+// The small-scene kernel reads u = col / W and v = row / H from tables; they are rebuilt (on the stream of the
+// render, followed by one synchronisation so that later renders on other streams may use them) only when the
+// frame size changes.
+static hipError_t ensure_uv_tables(mrt_ctx *ctx, int W, int H, hipStream_t st)
 {
-  if (mode == 1) {
-    const long n = (long)A.sc.ns + A.sc.nt;
-    (void)n;
-    mode = 2; // measured: with the primitive-side hierarchy the one-level tile kernel wins everywhere
+  if (ctx->uv_mem && ctx->uv_w == W && ctx->uv_h == H) return hipSuccess;
+  hipError_t e;
+  if (ctx->uv_mem) {
+    if ((e = hipDeviceSynchronize()) != hipSuccess) return e; // a render in flight may still read the old tables
+    (void)hipFree(ctx->uv_mem);
+    ctx->uv_mem = nullptr;
   }
+  const int nu = (W + 31) / 32 * 32; // whole tiles of up to 32 pixels
+  if ((e = hipMalloc((void **)&ctx->uv_mem, sizeof(float) * ((size_t)nu + H))) != hipSuccess) return e;
+  if ((e = mrt::launch_uv_table(ctx->uv_mem, nu, W, ctx->uv_mem + nu, H, H, st)) != hipSuccess) return e;
+  if ((e = hipStreamSynchronize(st)) != hipSuccess) return e;
+  ctx->uv_w = W; ctx->uv_h = H; ctx->uv_nu = nu;
+  return hipSuccess;
+}
+
+static hipError_t launch_by_mode(mrt_ctx *ctx, mrt::RenderArgs &A, hipStream_t st)
+{
+  int mode = ctx->cull;
+  const bool small = (long)A.sc.ns + A.sc.nt <= 64;
+  // measured: the small-scene kernel wins where it applies; with the primitive-side hierarchy the
+  // one-level tile kernel wins everywhere else
+  if (mode == 1) mode = small ? 5 : 2;
+  if (mode == 5 && !small) mode = 2;
   switch (mode) {
   case 0: return mrt::launch_render(A, st);
   case 2: return mrt::launch_render_cull(A, st);
   case 3: return mrt::launch_render_cull2(A, 4, st);
-  default: return mrt::launch_render_cull2(A, 8, st);
+  case 4: return mrt::launch_render_cull2(A, 8, st);
+  default: {
+    hipError_t e = ensure_uv_tables(ctx, A.W, A.H, st);
+    if (e != hipSuccess) return e;
+    A.utab = ctx->uv_mem; A.vtab = ctx->uv_mem + ctx->uv_nu;
+    return mrt::launch_render_small(A, st);
+  }
   }
 }
 
@@ -168,7 +200,7 @@ int mrt_ctx_set_option(mrt_ctx *ctx, int option, int value)
 {
   if (!ctx) return MRT_ERR_INVALID;
   if (option == MRT_OPT_CULL) {
-    if (value < 0 || value > 4) return fail(ctx, MRT_ERR_INVALID, "MRT_OPT_CULL takes 0..4");
+    if (value < 0 || value > 5) return fail(ctx, MRT_ERR_INVALID, "MRT_OPT_CULL takes 0..5");
     ctx->cull = value;
     return MRT_OK;
   }
@@ -232,6 +264,7 @@ int mrt_ctx_destroy(mrt_ctx *ctx)
   (void)hipSetDevice(ctx->device);
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
   if (ctx->scene_mem) (void)hipFree(ctx->scene_mem);
+  if (ctx->uv_mem) (void)hipFree(ctx->uv_mem);
   if (ctx->out_mem) (void)hipFree(ctx->out_mem);
   if (ctx->stats_dev) (void)hipFree(ctx->stats_dev);
   if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
@@ -485,7 +518,7 @@ int mrt_render_device(mrt_ctx *ctx, const mrt_camera *cam, const mrt_render_para
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   hipStream_t st = (hipStream_t)stream; // NULL = HIP's default stream, as everywhere in HIP
   if (A.stats) HIP_TRY(ctx, hipMemsetAsync(A.stats, 0, 8 * sizeof(unsigned long long), st));
-  HIP_TRY(ctx, launch_by_mode(ctx->cull, A, st));
+  HIP_TRY(ctx, launch_by_mode(ctx, A, st));
   return MRT_OK;
 }
 
@@ -511,7 +544,7 @@ int mrt_render(mrt_ctx *ctx, const mrt_camera *cam, const mrt_render_params *par
   A.stats = stats ? ctx->stats_dev : nullptr;
   if (A.stats) HIP_TRY(ctx, hipMemsetAsync(A.stats, 0, 8 * sizeof(unsigned long long), ctx->stream));
   HIP_TRY(ctx, hipEventRecord(ctx->ev0, ctx->stream));
-  HIP_TRY(ctx, launch_by_mode(ctx->cull, A, ctx->stream));
+  HIP_TRY(ctx, launch_by_mode(ctx, A, ctx->stream));
   HIP_TRY(ctx, hipEventRecord(ctx->ev1, ctx->stream));
   if (npix) {
     HIP_TRY(ctx, hipMemcpyAsync(rgb, A.rgb, npix * 12, hipMemcpyDeviceToHost, ctx->stream));

@@ -62,12 +62,19 @@ struct RenderArgs {
   // LDS plan (filled by the launcher)
   int32_t resident;                 // whole scene staged once
   int32_t s_cap, t_cap;             // primitives per LDS chunk
+  // small-scene kernel (mrt_small.hip): u = col / W and v = row / H tables, vector-store switch
+  const float *utab, *vtab;
+  int32_t wide;
   float cone_ext;                   // cull kernel: max |ray - tile centre ray| over a padded tile (launcher)
 };
 
 hipError_t launch_render_cull(const RenderArgs &args, hipStream_t stream);
 // two-level culling (mrt_cull2.hip); waves = 4 (32x32-pixel super-tiles) or 8 (64x32)
 hipError_t launch_render_cull2(const RenderArgs &args, int waves, hipStream_t stream);
+
+// scenes of at most 64 primitives (mrt_small.hip); needs args.utab / args.vtab
+hipError_t launch_render_small(const RenderArgs &args, hipStream_t stream);
+hipError_t launch_uv_table(float *utab, int nu, int W, float *vtab, int nv, int H, hipStream_t stream);
 
 // launchers (mrt_kernels.hip)
 hipError_t launch_render(const RenderArgs &args, hipStream_t stream);

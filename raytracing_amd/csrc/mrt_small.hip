@@ -1,0 +1,529 @@
+// mrt_small.hip -- render kernel for scenes of at most 64 primitives (the reference's own scene has 10).
+//
+// Same results as the other render kernels (same fp32 operations in the same order for everything that
+// reaches a buffer); what differs is how the work is laid over a wave64:
+//
+//   * a wave renders a tile of 8P x 8 pixels, each lane P horizontally adjacent pixels (P = 4: a lane's
+//     outputs are 48 + 16 + 16 contiguous bytes, written with five 16-byte stores).  Everything that is
+//     uniform over the tile -- the bound tests, the record fetches, the loop control -- is paid once per
+//     8P x 8 pixels, and the P independent pixels of a lane give the scheduler P dependency chains;
+//   * lane k also OWNS primitive k (spheres first, then triangles): it keeps the primitive's bound and the
+//     ray-independent terms of the exact tests (o - c, |o - c|^2 - r^2, k - n.o) in registers, tests the
+//     bound against the tile's cone / shadow bundle, and the survivors' terms are broadcast with v_readlane
+//     -- no memory access in the sphere loops, one 64-byte scalar load per surviving triangle;
+//   * u = col / W and v = row / H come from two tables computed once per frame size with the same IEEE
+//     division (uv_table_kernel) instead of 1 + P divisions per lane.
+//
+// Reference semantics: src/main.cu:60-104,122-157 (render / color_ray with MAX_RECURSION_DEPTH = 0),
+// core/sphere.cuh:32-73, core/triangle.cuh:77-103, core/light.cuh:135-178, core/material.cuh:63-75,134-158.
+
+#include "mrt_internal.h"
+#include "mrt_device.h"
+#include "mrt_cull_common.h"
+
+#include <cmath>
+#include <cstdlib>
+
+namespace mrt {
+
+__global__ void uv_table_kernel(float *utab, int nu, int W, float *vtab, int nv, int H)
+{
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < nu) utab[i] = float(i) / float(W); // src/main.cu:136
+  if (i < nv) vtab[i] = float(i) / float(H); // src/main.cu:137
+}
+
+hipError_t launch_uv_table(float *utab, int nu, int W, float *vtab, int nv, int H, hipStream_t stream)
+{
+  const int n = nu > nv ? nu : nv;
+  if (n <= 0) return hipSuccess;
+  hipLaunchKernelGGL(uv_table_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, utab, nu, W, vtab, nv, H);
+  return hipGetLastError();
+}
+
+// max over the wave with DPP row operations (no LDS traffic); the result is wave-uniform
+__device__ __forceinline__ float wave_max_dpp(float x)
+{
+#define MRT_DPP_MAX(ctrl, row_mask)                                                                              \
+  x = fmaxf(x, __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(x), __float_as_int(x), ctrl, row_mask, \
+                                                          0xf, false)))
+  MRT_DPP_MAX(0xB1, 0xf);  // quad_perm [1,0,3,2]
+  MRT_DPP_MAX(0x4E, 0xf);  // quad_perm [2,3,0,1]
+  MRT_DPP_MAX(0x141, 0xf); // row_half_mirror
+  MRT_DPP_MAX(0x140, 0xf); // row_mirror: every lane of a row of 16 holds the row's maximum
+  MRT_DPP_MAX(0x142, 0xa); // row_bcast:15 into rows 1 and 3
+  MRT_DPP_MAX(0x143, 0xc); // row_bcast:31 into rows 2 and 3: lane 63 holds the wave's maximum
+#undef MRT_DPP_MAX
+  return bcast(x, 63);
+}
+
+template <int P> struct VecOf;
+template <> struct VecOf<1> { using f = float; using i = int; };
+template <> struct VecOf<2> { using f = float2; using i = int2; };
+template <> struct VecOf<4> { using f = float4; using i = int4; };
+
+template <int P>
+__global__ __launch_bounds__(256) void render_small_kernel(RenderArgs A)
+{
+  const DevScene &sc = A.sc;
+  const DevCamera &cam = A.cam;
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int tx = lane & 7, ty = lane >> 3;
+  const int ns = sc.ns, nt = sc.nt; // ns + nt <= 64 (launcher)
+  constexpr int TW = 8 * P;         // tile width in pixels
+
+  const int tile_x = blockIdx.x * 4 + wave;
+  const int tile_y = blockIdx.y;
+  if (tile_x * TW >= A.W) return; // waves are independent: no barrier anywhere below
+  const int col0 = tile_x * TW + tx * P;
+  const int lrow = tile_y * 8 + ty;
+  const int lrow0 = tile_y * 8;
+  const int strip = lrow0 / A.strip_rows; // strips are multiples of 8 rows: a tile never straddles two
+  const int grow0 = (strip * A.nranks + A.rank) * A.strip_rows + (lrow0 - strip * A.strip_rows);
+  const int grow = grow0 + ty;
+  const bool valid_row = (lrow < A.local_rows) && (grow < A.H);
+
+  // ---- cone around the tile's rays, padded by one pixel on every side (covers the 121-spp offsets): every
+  //      ray of the padded tile is the centre ray plus an offset of norm <= cone_ext (launcher) ----
+  float cax, cay, caz, cosT, sinT;
+  {
+    const float rw = fast_rcp(float(A.W)), rh = fast_rcp(float(A.H)); // bound arithmetic: approximate is fine
+    const float um = (float(tile_x * TW) + 0.5f * float(TW - 1)) * rw, vm = (float(grow0) + 3.5f) * rh;
+    cax = ((cam.ux + um * cam.hx) + vm * cam.vx) - cam.ox;
+    cay = ((cam.uy + um * cam.hy) + vm * cam.vy) - cam.oy;
+    caz = ((cam.uz + um * cam.hz) + vm * cam.vz) - cam.oz;
+    const float inv = fast_rsq(dot3(cax, cay, caz, cax, cay, caz));
+    cax *= inv; cay *= inv; caz *= inv;
+    sinT = A.cone_ext * inv * (1.0f + 1e-4f) + 1e-6f;
+    cosT = fast_sqrt(fmaxf(1.0f - sinT * sinT, 0.0f)) * (1.0f - 1e-5f) - 1e-6f;
+    // a cone of 90 degrees or more (or a NaN camera) cannot cull: cos = -1 makes every ball pass
+    if (!(sinT < 0.99f) || !(cosT > 0.0f)) { cosT = -1.0f; sinT = 0.0f; }
+  }
+
+  // ---- the primitive this lane owns: bound, and the ray-independent terms of the exact primary tests ----
+  const bool own_s = lane < ns, own_t = (lane >= ns) && (lane < ns + nt);
+  float bx = 0.0f, by = 0.0f, bz = 0.0f, brad = 0.0f; // sphere centre + radius / triangle bound ball
+  float g0 = 0.0f, g1 = 0.0f, g2 = 0.0f;               // sphere centre / triangle plane normal
+  float e0 = 0.0f, e1 = 0.0f, e2 = 0.0f, e3 = 0.0f;    // sphere: o - c, |o - c|^2 - r^2;  triangle: e0 = k - n.o
+  float rr = 0.0f;                                     // sphere: r^2
+  int pobj = 0;
+  bool pass_primary = false;
+  if (own_s) {
+    bx = sc.sph_cx[lane]; by = sc.sph_cy[lane]; bz = sc.sph_cz[lane]; brad = sc.sph_r[lane];
+    pobj = sc.sph_obj[lane];
+    g0 = bx; g1 = by; g2 = bz;
+    e0 = cam.ox - bx; e1 = cam.oy - by; e2 = cam.oz - bz;
+    rr = brad * brad;
+    e3 = dot3(e0, e1, e2, e0, e1, e2) - rr;
+    const float wx = bx - cam.ox, wy = by - cam.oy, wz = bz - cam.oz;
+    const float L2 = dot3(wx, wy, wz, wx, wy, wz);
+    pass_primary = ball_may_touch_cone(wx, wy, wz, sphere_cull_radius(rr, L2), cax, cay, caz, cosT, sinT);
+  } else if (own_t) {
+    const int k = lane - ns;
+    bx = sc.tri_bx[k]; by = sc.tri_by[k]; bz = sc.tri_bz[k]; brad = sc.tri_br[k];
+    pobj = sc.tri_obj[k];
+    g0 = sc.tri[k]; g1 = sc.tri[nt + k]; g2 = sc.tri[2 * nt + k];
+    e0 = sc.tri[3 * nt + k] - dot3(cam.ox, cam.oy, cam.oz, g0, g1, g2);
+    pass_primary = ball_may_touch_cone(bx - cam.ox, by - cam.oy, bz - cam.oz, brad * CULL_REL + CULL_ABS, cax, cay, caz,
+                                       cosT, sinT);
+  }
+  const unsigned long long smask_all = ns >= 64 ? ~0ull : ((1ull << ns) - 1ull);
+  const unsigned long long primary_mask = __ballot(pass_primary);
+
+  float accr[P], accg[P], accb[P];
+  int out_id[P];
+  float out_t[P];
+  bool valid[P];
+#pragma unroll
+  for (int p = 0; p < P; ++p) {
+    accr[p] = 0.0f; accg[p] = 0.0f; accb[p] = 0.0f;
+    out_id[p] = -1; out_t[p] = MRT_INF;
+    valid[p] = valid_row && (col0 + p < A.W);
+  }
+  unsigned int n_shadow = 0, n_hit = 0, n_occl = 0;
+  unsigned int n_exact = 0, n_clusters = 0; // wave-uniform diagnostics (lane 0 reports them)
+  const int nsamp = A.spp;
+  const float DIVW = 13.0f, DIVH = 13.0f;
+
+  // u, v of the lane's pixels: tables hold float(i) / float(W) and float(i) / float(H) (uv_table_kernel)
+  float u0[P];
+  {
+    const typename VecOf<P>::f uu = *reinterpret_cast<const typename VecOf<P>::f *>(A.utab + col0);
+    const float *up = reinterpret_cast<const float *>(&uu);
+#pragma unroll
+    for (int p = 0; p < P; ++p) u0[p] = up[p];
+  }
+  const float v = A.vtab[grow < A.H ? grow : A.H - 1]; // rows beyond the frame are never written
+
+  for (int sidx = 0; sidx < nsamp; ++sidx) {
+    float offx = 0.0f, offy = 0.0f;
+    if (nsamp > 1) { // pipeline/multisample_mesh.cuh:23-30
+      int r = sidx / 11, c = sidx - r * 11;
+      offy = (-1.0f + 2.0f * float(r + 1) / DIVH) / float(A.H);
+      offx = (-1.0f + 2.0f * float(c + 1) / DIVW) / float(A.W);
+    }
+    // ---- primary rays: pipeline/viewport.cuh:30-34 ----
+    float dx[P], dy[P], dz[P], aa[P], best_t[P];
+    int best_obj[P], best_k[P];
+    const float sv = nsamp > 1 ? v + offy : v;
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+      const float su = nsamp > 1 ? u0[p] + offx : u0[p];
+      dx[p] = ((cam.ux + su * cam.hx) + sv * cam.vx) - cam.ox;
+      dy[p] = ((cam.uy + su * cam.hy) + sv * cam.vy) - cam.oy;
+      dz[p] = ((cam.uz + su * cam.hz) + sv * cam.vz) - cam.oz;
+      aa[p] = dot3(dx[p], dy[p], dz[p], dx[p], dy[p], dz[p]);
+      best_t[p] = MRT_INF; best_obj[p] = 0x7fffffff; best_k[p] = -1;
+    }
+
+    // ---- closest hit over the surviving spheres: src/main.cu:60-77, core/sphere.cuh:32-73, [0.01, inf] ----
+    {
+      unsigned long long mask = primary_mask & smask_all;
+      n_clusters++; n_exact += __popcll(primary_mask);
+      while (mask) {
+        const int j = __builtin_ctzll(mask);
+        mask &= mask - 1;
+        const float ocx = bcast(e0, j), ocy = bcast(e1, j), ocz = bcast(e2, j), c = bcast(e3, j);
+        const int obj = __builtin_amdgcn_readlane(pobj, j);
+#pragma unroll
+        for (int p = 0; p < P; ++p) {
+          const float b = dot3(ocx, ocy, ocz, dx[p], dy[p], dz[p]);
+          const float disc = b * b - aa[p] * c;
+          if (disc >= 0.0f) {
+            float t;
+            if (sphere_roots(aa[p], b, disc, 0.01f, MRT_INF, t)) {
+              if (t < best_t[p] || (t == best_t[p] && t < MRT_INF && obj < best_obj[p])) {
+                best_t[p] = t; best_obj[p] = obj; best_k[p] = j;
+              }
+            }
+          }
+        }
+      }
+    }
+    // ---- ... and triangles: core/triangle.cuh:77-103 ----
+    {
+      unsigned long long mask = ns >= 64 ? 0ull : (primary_mask >> ns);
+      while (mask) {
+        const int j = __builtin_ctzll(mask);
+        mask &= mask - 1;
+        const float *q = sc.tri_rec + 16 * j; // wave-uniform address: one s_load_dwordx16
+        const float pnx = q[0], pny = q[1], pnz = q[2];
+        const float num = bcast(e0, ns + j);
+        const int obj = __builtin_amdgcn_readlane(pobj, ns + j);
+#pragma unroll
+        for (int p = 0; p < P; ++p) {
+          const float rdn = dot3(dx[p], dy[p], dz[p], pnx, pny, pnz);
+          const float t = num / rdn;
+          const float px = cam.ox + t * dx[p], py = cam.oy + t * dy[p], pz = cam.oz + t * dz[p];
+          const float d0 = dot3(q[4], q[5], q[6], px, py, pz) - q[7];
+          const float d1 = dot3(q[8], q[9], q[10], px, py, pz) - q[11];
+          const float d2 = dot3(q[12], q[13], q[14], px, py, pz) - q[15];
+          const bool hit = (rdn != 0.0f) & (d0 > -1e-6f) & (d1 > -1e-6f) & (d2 > -1e-6f) & (0.01f <= t) & (t <= MRT_INF);
+          if (hit) {
+            if (t < best_t[p] || (t == best_t[p] && t < MRT_INF && obj < best_obj[p])) {
+              best_t[p] = t; best_obj[p] = obj; best_k[p] = ns + j;
+            }
+          }
+        }
+      }
+    }
+
+    // ---- hit records of the winners (core/sphere.cuh:45-47, core/triangle.cuh:96-97); the winner's centre /
+    //      plane normal comes from the owning lane's registers ----
+    bool have_hit[P], any_hit_lane = false;
+    float hpx[P], hpy[P], hpz[P], hnx[P], hny[P], hnz[P];
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+      have_hit[p] = best_k[p] >= 0;
+      any_hit_lane |= have_hit[p];
+      hpx[p] = 0.0f; hpy[p] = 0.0f; hpz[p] = 0.0f; hnx[p] = 0.0f; hny[p] = 0.0f; hnz[p] = 0.0f;
+    }
+    const bool tile_hit = __any(any_hit_lane);
+    if (tile_hit) {
+#pragma unroll
+      for (int p = 0; p < P; ++p) {
+        const int k = have_hit[p] ? best_k[p] : lane;
+        const float w0 = __shfl(g0, k, 64), w1 = __shfl(g1, k, 64), w2 = __shfl(g2, k, 64);
+        if (have_hit[p]) {
+          hpx[p] = cam.ox + best_t[p] * dx[p]; hpy[p] = cam.oy + best_t[p] * dy[p]; hpz[p] = cam.oz + best_t[p] * dz[p];
+          if (best_k[p] < ns) {
+            float nx = hpx[p] - w0, ny = hpy[p] - w1, nz = hpz[p] - w2;
+            normalize3(nx, ny, nz);
+            hnx[p] = nx; hny[p] = ny; hnz[p] = nz;
+          } else {
+            const bool front = dot3(dx[p], dy[p], dz[p], w0, w1, w2) < 0;
+            hnx[p] = front ? w0 : -w0; hny[p] = front ? w1 : -w1; hnz[p] = front ? w2 : -w2;
+          }
+          if (valid[p]) n_hit++;
+        }
+      }
+    }
+
+    // ---- shadow rays + direct light: core/light.cuh:135-178 ----
+    float lr[P], lg[P], lb[P];
+    bool have_light[P];
+#pragma unroll
+    for (int p = 0; p < P; ++p) { lr[p] = 0.0f; lg[p] = 0.0f; lb[p] = 0.0f; have_light[p] = false; }
+    if (tile_hit) {
+      // ball around the tile's hit points: centre = the first hit point found, radius = the farthest one
+      Bundle B;
+      {
+        float mx = 0.0f, my = 0.0f, mz = 0.0f;
+        bool found = false;
+#pragma unroll
+        for (int p = 0; p < P; ++p) {
+          const unsigned long long hm = __ballot(have_hit[p]);
+          if (!found && hm) {
+            const int first = __builtin_ctzll(hm);
+            mx = bcast(hpx[p], first); my = bcast(hpy[p], first); mz = bcast(hpz[p], first);
+            found = true;
+          }
+        }
+        B.mx = mx; B.my = my; B.mz = mz;
+        float e2max = 0.0f;
+#pragma unroll
+        for (int p = 0; p < P; ++p) {
+          const float ex = hpx[p] - mx, ey = hpy[p] - my, ez = hpz[p] - mz;
+          e2max = fmaxf(e2max, have_hit[p] ? dot3(ex, ey, ez, ex, ey, ez) : 0.0f);
+        }
+        B.rho = fast_sqrt(wave_max_dpp(e2max)) * CULL_REL + CULL_ABS;
+      }
+      // distance bound from the bundle centre for the sphere this lane owns (>= |hit point - centre|)
+      float Lm2 = 0.0f;
+      if (own_s) {
+        const float wx = bx - B.mx, wy = by - B.my, wz = bz - B.mz;
+        const float Lm = fast_sqrt(dot3(wx, wy, wz, wx, wy, wz)) * CULL_REL + B.rho;
+        Lm2 = Lm * Lm;
+      }
+      const float reff_shadow = own_s ? sphere_cull_radius(rr, Lm2) : brad;
+
+      for (int li = 0; li < sc.nl; ++li) {
+        const int lkind = sc.light_kind[li];
+        const float lvx = sc.light_vec[3 * li], lvy = sc.light_vec[3 * li + 1], lvz = sc.light_vec[3 * li + 2];
+        // per-pixel shadow ray and the light's "hit record" (ray_from: core/light.cuh:73-81 / :47-53)
+        float sdx[P], sdy[P], sdz[P], lnx[P], lny[P], lnz[P], sa[P];
+        float tl;
+        bool need[P], open[P], any_open = false;
+        if (lkind == 0) {
+          tl = MRT_INF;
+          B.point = false;
+          B.Dx = -lvx; B.Dy = -lvy; B.Dz = -lvz;
+#pragma unroll
+          for (int p = 0; p < P; ++p) {
+            sdx[p] = -lvx; sdy[p] = -lvy; sdz[p] = -lvz;
+            lnx[p] = lvx; lny[p] = lvy; lnz[p] = lvz;
+          }
+        } else {
+          tl = 1.0f;
+          B.point = true;
+          B.Dx = lvx - B.mx; B.Dy = lvy - B.my; B.Dz = lvz - B.mz;
+#pragma unroll
+          for (int p = 0; p < P; ++p) {
+            sdx[p] = lvx - hpx[p]; sdy[p] = lvy - hpy[p]; sdz[p] = lvz - hpz[p];
+            float nx = hpx[p] - lvx, ny = hpy[p] - lvy, nz = hpz[p] - lvz;
+            normalize3(nx, ny, nz);
+            lnx[p] = nx; lny[p] = ny; lnz[p] = nz;
+          }
+        }
+        B.DD = dot3(B.Dx, B.Dy, B.Dz, B.Dx, B.Dy, B.Dz);
+#pragma unroll
+        for (int p = 0; p < P; ++p) {
+          sa[p] = dot3(sdx[p], sdy[p], sdz[p], sdx[p], sdy[p], sdz[p]);
+          // the light must not shine through the surface, core/light.cuh:148
+          need[p] = have_hit[p] && !(dot3(sdx[p], sdy[p], sdz[p], hnx[p], hny[p], hnz[p]) < 0);
+          open[p] = need[p];
+          any_open |= open[p];
+        }
+
+        if (__any(any_open)) {
+          // which primitives can touch one of the tile's shadow rays (interval [1e-3, t_light], core/light.cuh:28-33)
+          const bool pass = (own_s || own_t) && bundle_may_touch(B, bx, by, bz, reff_shadow);
+          const unsigned long long shadow_mask = __ballot(pass);
+          n_clusters++; n_exact += __popcll(shadow_mask);
+          unsigned long long mask = shadow_mask & smask_all;
+          bool go = true;
+          while (mask && go) {
+            const int j = __builtin_ctzll(mask);
+            mask &= mask - 1;
+            const float scx = bcast(g0, j), scy = bcast(g1, j), scz = bcast(g2, j), srr = bcast(rr, j);
+            bool still = false;
+#pragma unroll
+            for (int p = 0; p < P; ++p) {
+              const float ocx = hpx[p] - scx, ocy = hpy[p] - scy, ocz = hpz[p] - scz;
+              const float b = dot3(ocx, ocy, ocz, sdx[p], sdy[p], sdz[p]);
+              const float c = dot3(ocx, ocy, ocz, ocx, ocy, ocz) - srr;
+              const float disc = b * b - sa[p] * c;
+              if (open[p] && disc >= 0.0f) {
+                float t;
+                if (sphere_roots(sa[p], b, disc, 1e-3f, tl, t)) open[p] = false;
+              }
+              still |= open[p];
+            }
+            go = __any(still); // every shadow ray of the tile is blocked: stop
+          }
+          mask = (go && ns < 64) ? (shadow_mask >> ns) : 0ull;
+          while (mask && go) {
+            const int j = __builtin_ctzll(mask);
+            mask &= mask - 1;
+            const float *q = sc.tri_rec + 16 * j;
+            const float pnx = q[0], pny = q[1], pnz = q[2], kp = q[3];
+            bool still = false;
+#pragma unroll
+            for (int p = 0; p < P; ++p) {
+              const float rdn = dot3(sdx[p], sdy[p], sdz[p], pnx, pny, pnz);
+              const float t = (kp - dot3(hpx[p], hpy[p], hpz[p], pnx, pny, pnz)) / rdn;
+              const float px = hpx[p] + t * sdx[p], py = hpy[p] + t * sdy[p], pz = hpz[p] + t * sdz[p];
+              const float d0 = dot3(q[4], q[5], q[6], px, py, pz) - q[7];
+              const float d1 = dot3(q[8], q[9], q[10], px, py, pz) - q[11];
+              const float d2 = dot3(q[12], q[13], q[14], px, py, pz) - q[15];
+              const bool h = (rdn != 0.0f) & (d0 > -1e-6f) & (d1 > -1e-6f) & (d2 > -1e-6f) & (1e-3f <= t) & (t <= tl);
+              if (open[p] && h) open[p] = false;
+              still |= open[p];
+            }
+            go = __any(still);
+          }
+        }
+
+        const float lcr = sc.light_rgb[3 * li], lcg = sc.light_rgb[3 * li + 1], lcb = sc.light_rgb[3 * li + 2];
+#pragma unroll
+        for (int p = 0; p < P; ++p) {
+          if (need[p] && valid[p]) { n_shadow++; if (!open[p]) n_occl++; }
+          if (open[p]) {
+            // light_bounce with the LIGHT's normal, as the reference passes it (core/light.cuh:164-168)
+            const float dn = dot3(sdx[p], sdy[p], sdz[p], lnx[p], lny[p], lnz[p]);
+            float cr, cg, cb;
+            if (sc.mat_kind[best_obj[p]] == 0) { // DiffuseMaterial::light_bounce, core/material.cuh:63-75
+              const float scale = -dn;
+              if (scale > 0.0f) { cr = scale * lcr; cg = scale * lcg; cb = scale * lcb; }
+              else { cr = 0.0f; cg = 0.0f; cb = 0.0f; }
+            } else {                              // MetallicMaterial::light_bounce, core/material.cuh:134-158
+              const float s2 = 2.0f * dn;
+              const float rx = sdx[p] - s2 * lnx[p], ry = sdy[p] - s2 * lny[p], rz = sdz[p] - s2 * lnz[p];
+              if (dot3(rx, ry, rz, dx[p], dy[p], dz[p]) < -0.99f) { cr = lcr; cg = lcg; cb = lcb; }
+              else { cr = 0.001f; cg = 0.001f; cb = 0.001f; }
+            }
+            if (have_light[p]) { lr[p] += cr; lg[p] += cg; lb[p] += cb; }
+            else { lr[p] = cr; lg[p] = cg; lb[p] = cb; have_light[p] = true; }
+          }
+        }
+      }
+    }
+
+    // ---- combine: src/main.cu:91-104 with MAX_RECURSION_DEPTH = 0 ----
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+      float cr, cg, cb;
+      if (have_hit[p]) {
+        const float *m = sc.mat_rgb + 3 * best_obj[p];
+        const float mr = m[0], mg = m[1], mb = m[2];
+        const float inc = 0.01f; // what the depth-1 call returns, src/main.cu:51-53
+        if (have_light[p]) { cr = inc * mr + lr[p] * mr; cg = inc * mg + lg[p] * mg; cb = inc * mb + lb[p] * mb; }
+        else { cr = inc * mr; cg = inc * mg; cb = inc * mb; }
+      } else {
+        float nx = dx[p], ny = dy[p], nz = dz[p];
+        normalize3(nx, ny, nz);
+        const float y = 0.5f * (ny + 1.0f);
+        const float w0 = 1.0f - y;
+        cr = w0 * 1.0f + y * 0.5f; cg = w0 * 1.0f + y * 0.7f; cb = w0 * 1.0f + y * 1.0f;
+      }
+      accr[p] += cr; accg[p] += cg; accb[p] += cb; // src/main.cu:151
+      out_id[p] = have_hit[p] ? best_obj[p] : -1;
+      out_t[p] = best_t[p];
+    }
+  }
+
+  // ---- framebuffer: src/main.cu:155 (x / 1.0f == x, so the division is skipped for one sample) ----
+  if (nsamp > 1) {
+    const float fn = float(nsamp);
+#pragma unroll
+    for (int p = 0; p < P; ++p) { accr[p] = accr[p] / fn; accg[p] = accg[p] / fn; accb[p] = accb[p] / fn; }
+  }
+  const size_t pix0 = size_t(lrow) * A.W + col0;
+  if (A.wide && valid_row && col0 + P <= A.W) {
+    // the lane's 3P floats / P ints / P floats are contiguous and 4P-byte aligned (launcher checks W and pointers)
+    using VF = typename VecOf<P>::f;
+    using VI = typename VecOf<P>::i;
+    float o[3 * P];
+#pragma unroll
+    for (int p = 0; p < P; ++p) { o[3 * p] = accr[p]; o[3 * p + 1] = accg[p]; o[3 * p + 2] = accb[p]; }
+    VF *dst = reinterpret_cast<VF *>(A.rgb + 3 * pix0);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) dst[k] = *reinterpret_cast<const VF *>(&o[P * k]);
+    if (A.id) *reinterpret_cast<VI *>(A.id + pix0) = *reinterpret_cast<const VI *>(&out_id[0]);
+    if (A.t) *reinterpret_cast<VF *>(A.t + pix0) = *reinterpret_cast<const VF *>(&out_t[0]);
+  } else {
+#pragma unroll
+    for (int p = 0; p < P; ++p)
+      if (valid[p]) {
+        A.rgb[3 * (pix0 + p) + 0] = accr[p];
+        A.rgb[3 * (pix0 + p) + 1] = accg[p];
+        A.rgb[3 * (pix0 + p) + 2] = accb[p];
+        if (A.id) A.id[pix0 + p] = out_id[p];
+        if (A.t) A.t[pix0 + p] = out_t[p];
+      }
+  }
+
+  if (A.stats) {
+    unsigned int nvalid = 0;
+#pragma unroll
+    for (int p = 0; p < P; ++p) nvalid += valid[p] ? 1u : 0u;
+    unsigned int v4[4] = {nvalid * (unsigned)nsamp, n_shadow, n_hit, n_occl};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      unsigned int x = v4[k];
+      for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, 64);
+      if (lane == 0 && x) atomicAdd(&A.stats[k], (unsigned long long)x);
+    }
+    if (lane == 0) {
+      atomicAdd(&A.stats[4], (unsigned long long)n_exact);
+      atomicAdd(&A.stats[5], (unsigned long long)n_clusters);
+    }
+  }
+}
+
+template <int P>
+static hipError_t launch_small(RenderArgs &A, hipStream_t stream)
+{
+  // largest offset of a ray of the padded tile (pixels -1..8P horizontally, -1..8 vertically) from the tile's
+  // centre ray, in double, rounded up
+  {
+    const double hw = (4.0 * P + 0.5) / A.W, hh = 4.5 / A.H;
+    const double hx[3] = {hw * A.cam.hx, hw * A.cam.hy, hw * A.cam.hz};
+    const double hy[3] = {hh * A.cam.vx, hh * A.cam.vy, hh * A.cam.vz};
+    double p = 0, m = 0;
+    for (int k = 0; k < 3; ++k) { p += (hx[k] + hy[k]) * (hx[k] + hy[k]); m += (hx[k] - hy[k]) * (hx[k] - hy[k]); }
+    A.cone_ext = float(std::sqrt(p > m ? p : m) * 1.001);
+  }
+  // vector stores need every lane's first pixel on a 4P-byte boundary in all three buffers
+  const uintptr_t align = 4 * P - 1;
+  A.wide = (A.W % P == 0) && ((uintptr_t)A.rgb & align) == 0 && ((uintptr_t)A.id & align) == 0 &&
+           ((uintptr_t)A.t & align) == 0;
+  const int tiles_x = (A.W + 8 * P - 1) / (8 * P), tiles_y = (A.local_rows + 7) / 8;
+  if (tiles_x == 0 || tiles_y == 0) return hipSuccess;
+  hipLaunchKernelGGL(render_small_kernel<P>, dim3((tiles_x + 3) / 4, tiles_y), dim3(256), 0, stream, A);
+  return hipGetLastError();
+}
+
+int small_pixels_per_lane()
+{
+  static const int v = [] {
+    const char *e = getenv("MRT_SMALL_P");
+    const int x = e ? atoi(e) : 2; // measured on C2: 2 pixels per lane is the fastest
+    return (x == 1 || x == 2 || x == 4) ? x : 2;
+  }();
+  return v;
+}
+
+hipError_t launch_render_small(const RenderArgs &in, hipStream_t stream)
+{
+  RenderArgs A = in;
+  if (A.sc.ns + A.sc.nt > 64 || !A.utab || !A.vtab) return hipErrorInvalidValue;
+  switch (small_pixels_per_lane()) {
+  case 1: return launch_small<1>(A, stream);
+  case 4: return launch_small<4>(A, stream);
+  default: return launch_small<2>(A, stream);
+  }
+}
+
+} // namespace mrt

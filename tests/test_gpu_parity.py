@@ -19,13 +19,14 @@ GOLD = os.path.join(os.path.dirname(__file__), "golden")
 RGB_TOL = 1.0 / 255.0
 
 
-KERNEL_MODES = {"brute": 0, "cull": 2, "cull2x4": 3, "cull2x8": 4}
+KERNEL_MODES = {"brute": 0, "cull": 2, "cull2x4": 3, "cull2x8": 4, "small": 5}
 
 
 @pytest.fixture(params=list(KERNEL_MODES), autouse=True)
 def kernel_mode(request, gpu_ctx):
     """Every test runs against every render kernel: brute force (walks every primitive for every ray like
-    the reference loops), one-level tile culling, two-level tile culling with 4 and 8 waves."""
+    the reference loops), one-level tile culling, two-level tile culling with 4 and 8 waves, and the small-scene kernel (which
+    hands scenes of more than 64 primitives to the one-level kernel)."""
     gpu_ctx.set_cull(KERNEL_MODES[request.param])
     yield request.param
     gpu_ctx.set_cull(1)
