@@ -39,6 +39,9 @@ struct mrt_ctx {
   // u = col / W, v = row / H tables of the small-scene kernel, for the frame size of the last render
   float *uv_mem = nullptr;
   int uv_w = 0, uv_h = 0, uv_nu = 0;
+  // host copy of the triangles of a small scene (16 floats each, device order): the small-scene kernel's
+  // launcher derives the camera-dependent culling functions from it for every render
+  std::vector<float> small_tri16;
 };
 
 static thread_local std::string g_create_err;
@@ -113,7 +116,7 @@ static hipError_t launch_by_mode(mrt_ctx *ctx, mrt::RenderArgs &A, hipStream_t s
     hipError_t e = ensure_uv_tables(ctx, A.W, A.H, st);
     if (e != hipSuccess) return e;
     A.utab = ctx->uv_mem; A.vtab = ctx->uv_mem + ctx->uv_nu;
-    return mrt::launch_render_small(A, st);
+    return mrt::launch_render_small(A, ctx->small_tri16.data(), st);
   }
   }
 }
@@ -337,6 +340,69 @@ static void tri_bound(const float q[16], float out[4])
   out[3] = std::nextafter((float)rad, INFINITY);
 }
 
+// ---- shadow-ray edge functions (small scenes; scene and lights only, built once per upload) ----
+// Shadow ray of light l from hit point p, p' the point where it meets the triangle's plane (n, k):
+// e_i(p') rdn = H_i(p), affine in p, with rdn = n.sd (directional light, sd = -direction) or n.(L - p) (point
+// light at L); for a ray the exact test accepts, sign(rdn) is fixed: sign(n.sd), resp. sign(n.L - k).
+// Stored per edge: g = s grad H_i, off = s H_i(0), gn >= |g|_1, and margin coefficients a, b; then
+//    g.m + off + rho gn + margin < 0   =>   no shadow ray from the ball (m, rho) of hit points passes edge i,
+// margin = a + b Pmax (directional), (|L|_1 + Pmax)(a + b Pmax) (point), Pmax >= |hit point|_1.  The margins
+// are 1e-4 of the magnitudes entering the exact test (which rounds at 6e-8) plus its own -1e-6 tolerance.
+// Slots 21, 22: point lights only cull while |n.L - k| > slot21' + slot22 Pmax (a light in the plane breaks
+// the sign argument); stored as |n.L - k| - thr0 and thr1.
+enum { SH_STRIDE = 23, SMALL_MAX_SHADOW_LIGHTS = 4 };
+
+static void shadow_functions(const float q[16], int kind, const float lv[3], float out[SH_STRIDE])
+{
+  auto dot = [](const double *a, const double *b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; };
+  auto n1f = [](const double *a) { return std::fabs(a[0]) + std::fabs(a[1]) + std::fabs(a[2]); };
+  auto up = [](double x) { return (float)(x * (1.0 + 1e-6)); }; // magnitudes: round up
+  const double n[3] = {q[0], q[1], q[2]}, kp = q[3], nn1 = n1f(n);
+  const double L[3] = {lv[0], lv[1], lv[2]};
+  double sg, rdn = 0, nlk = 0, S0 = 0;
+  bool always = false;
+  if (kind == MRT_LIGHT_DIRECTIONAL) {
+    // the sign the kernel sees: same fp32 expression as the exact test's denominator
+    const float sdx = -lv[0], sdy = -lv[1], sdz = -lv[2];
+    const float rdnf = sdx * q[0] + (sdy * q[1] + sdz * q[2]);
+    sg = rdnf >= 0.0f ? 1.0 : -1.0;
+    always = (rdnf == 0.0f); // the exact test rejects rdn == 0
+    const double sd[3] = {-L[0], -L[1], -L[2]};
+    rdn = dot(sd, n);
+    S0 = n1f(sd);
+    out[21] = INFINITY;
+    out[22] = 0.0f;
+  } else {
+    nlk = dot(n, L) - kp;
+    sg = nlk >= 0 ? 1.0 : -1.0;
+    out[21] = (float)((std::fabs(nlk) - 1e-5 * (std::fabs(kp) + nn1 * n1f(L))) * (1.0 - 1e-6));
+    out[22] = up(1e-5 * nn1);
+  }
+  for (int i = 0; i < 3; ++i) {
+    const double m[3] = {q[4 + 4 * i], q[5 + 4 * i], q[6 + 4 * i]}, c = q[7 + 4 * i], m1 = n1f(m);
+    double g[3], off, a, b;
+    if (kind == MRT_LIGHT_DIRECTIONAL) {
+      const double sd[3] = {-L[0], -L[1], -L[2]};
+      const double mu = dot(m, sd), R0 = std::fabs(rdn);
+      for (int x = 0; x < 3; ++x) g[x] = sg * (rdn * m[x] - mu * n[x]);
+      off = sg * (kp * mu - c * rdn);
+      a = 1e-6 * R0 + 1e-4 * (std::fabs(c) * R0 + m1 * S0 * std::fabs(kp));
+      b = 1e-4 * m1 * (R0 + S0 * nn1);
+    } else {
+      const double mL = dot(m, L), nL = dot(n, L), cm = c - mL;
+      for (int x = 0; x < 3; ++x) g[x] = sg * (nlk * m[x] + cm * n[x]);
+      off = sg * (kp * mL - c * nL);
+      a = 1e-6 * nn1 + 1e-4 * (std::fabs(c) * nn1 + m1 * std::fabs(kp));
+      b = 2e-4 * m1 * nn1;
+    }
+    if (always) { g[0] = g[1] = g[2] = 0; off = -3.0e38; a = 0; b = 0; }
+    out[7 * i + 0] = (float)g[0]; out[7 * i + 1] = (float)g[1]; out[7 * i + 2] = (float)g[2];
+    out[7 * i + 3] = (float)off;
+    out[7 * i + 4] = up(n1f(g));
+    out[7 * i + 5] = up(a); out[7 * i + 6] = up(b);
+  }
+}
+
 int mrt_triangle_bound(const float tri16[16], float out4[4])
 {
   if (!tri16 || !out4) return MRT_ERR_INVALID;
@@ -377,6 +443,9 @@ int mrt_scene_upload(mrt_ctx *ctx, const mrt_scene_desc *s)
   auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
   const size_t o_cx = take(ns * 4), o_cy = take(ns * 4), o_cz = take(ns * 4), o_r = take(ns * 4), o_so = take(ns * 4);
   const size_t o_tri = take(nt * 16 * 4), o_to = take(nt * 4), o_tb = take(nt * 4 * 4), o_trec = take(nt * 64);
+  const bool small = ns + nt <= 64;
+  const size_t nls = small ? std::min<size_t>(nl, SMALL_MAX_SHADOW_LIGHTS) : 0;
+  const size_t o_shfn = take(nls * SH_STRIDE * nt * 4);
   const size_t ncs = (ns + 63) / 64, nct = (nt + 63) / 64;
   const size_t o_cs = take(ncs * 16), o_ct = take(nct * 16);
   const size_t nscs = (ncs + 63) / 64, nsct = (nct + 63) / 64;
@@ -426,6 +495,16 @@ int mrt_scene_upload(mrt_ctx *ctx, const mrt_scene_desc *s)
       for (int k = 0; k < 4; ++k) bnd[k * nt + i] = tb[4 * g + k];
       to[i] = s->tri_obj[g];
     }
+    // small scenes: shadow-ray functions per (light, triangle), and a host copy of the triangles
+    float *shfn = (float *)(img.data() + o_shfn);
+    for (size_t l = 0; l < nls; ++l)
+      for (size_t i = 0; i < nt; ++i) {
+        float f[SH_STRIDE];
+        shadow_functions(rec + 16 * i, s->light_kind[l], s->light_vec + 3 * l, f);
+        for (int k = 0; k < SH_STRIDE; ++k) shfn[(l * SH_STRIDE + k) * nt + i] = f[k];
+      }
+    try { if (small) ctx->small_tri16.assign(rec, rec + 16 * nt); else ctx->small_tri16.clear(); }
+    catch (...) { return fail(ctx, MRT_ERR_INVALID, "out of host memory"); }
     float *ct = (float *)(img.data() + o_ct);
     cluster_bounds(bnd, bnd + nt, bnd + 2 * nt, bnd + 3 * nt, nt, ct);
     cluster_bounds(ct, ct + nct, ct + 2 * nct, ct + 3 * nct, nct, (float *)(img.data() + o_sct));
@@ -450,6 +529,7 @@ int mrt_scene_upload(mrt_ctx *ctx, const mrt_scene_desc *s)
   d.tri = (const float *)(b + o_tri);   d.tri_obj = (const int32_t *)(b + o_to); d.nt = (int32_t)nt;
   d.tri_bx = (const float *)(b + o_tb); d.tri_by = d.tri_bx + nt; d.tri_bz = d.tri_bx + 2 * nt; d.tri_br = d.tri_bx + 3 * nt;
   d.tri_rec = (const float *)(b + o_trec);
+  d.tri_shfn = (const float *)(b + o_shfn); d.nls = (int32_t)nls;
   d.sph_clu = (const float *)(b + o_cs); d.ncs = (int32_t)ncs;
   d.tri_clu = (const float *)(b + o_ct); d.nct = (int32_t)nct;
   d.sph_sclu = (const float *)(b + o_scs); d.nscs = (int32_t)nscs;

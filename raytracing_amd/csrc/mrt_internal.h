@@ -22,6 +22,10 @@ struct DevScene {
   // the same 16 floats per triangle, contiguous (64 B records), for wave-uniform fetches of the few
   // triangles that survive culling (one s_load_dwordx16 instead of 16 strided scalar loads)
   const float *tri_rec;
+  // shadow-ray edge functions of the first nls lights, [light][23][triangle] (scenes of <= 64 primitives only;
+  // mrt_api.cpp shadow_functions, used by mrt_small.hip)
+  const float *tri_shfn;
+  int32_t nls;
   // bounding balls of runs of 64 consecutive primitives (primitives are stored in Morton order):
   // 4 streams (x, y, z, r) of ncs / nct floats each
   const float *sph_clu, *tri_clu;
@@ -73,7 +77,8 @@ hipError_t launch_render_cull(const RenderArgs &args, hipStream_t stream);
 hipError_t launch_render_cull2(const RenderArgs &args, int waves, hipStream_t stream);
 
 // scenes of at most 64 primitives (mrt_small.hip); needs args.utab / args.vtab
-hipError_t launch_render_small(const RenderArgs &args, hipStream_t stream);
+// host_tri16: host copy of the triangles (16 floats each, device order), for the per-render primary functions
+hipError_t launch_render_small(const RenderArgs &args, const float *host_tri16, hipStream_t stream);
 hipError_t launch_uv_table(float *utab, int nu, int W, float *vtab, int nv, int H, hipStream_t stream);
 
 // launchers (mrt_kernels.hip)

@@ -3,16 +3,30 @@
 // Same results as the other render kernels (same fp32 operations in the same order for everything that
 // reaches a buffer); what differs is how the work is laid over a wave64:
 //
-//   * a wave renders a tile of 8P x 8 pixels, each lane P horizontally adjacent pixels (P = 4: a lane's
-//     outputs are 48 + 16 + 16 contiguous bytes, written with five 16-byte stores).  Everything that is
-//     uniform over the tile -- the bound tests, the record fetches, the loop control -- is paid once per
-//     8P x 8 pixels, and the P independent pixels of a lane give the scheduler P dependency chains;
-//   * lane k also OWNS primitive k (spheres first, then triangles): it keeps the primitive's bound and the
-//     ray-independent terms of the exact tests (o - c, |o - c|^2 - r^2, k - n.o) in registers, tests the
-//     bound against the tile's cone / shadow bundle, and the survivors' terms are broadcast with v_readlane
-//     -- no memory access in the sphere loops, one 64-byte scalar load per surviving triangle;
+//   * a wave renders a tile of 8P x 8 pixels, each lane P horizontally adjacent pixels (a lane's outputs are
+//     contiguous: 3P + P + P floats, vector stores).  Everything uniform over the tile -- bound tests, record
+//     fetches, loop control -- is paid once per 8P x 8 pixels;
+//   * lane k also OWNS primitive k (spheres first, then triangles): it keeps the ray-independent terms of the
+//     exact tests (o - c, |o - c|^2 - r^2, k - n.o) in registers and tests the primitive's bound against the
+//     tile; the survivors' terms are broadcast with v_readlane -- no memory access in the sphere loops, one
+//     64-byte scalar load per surviving triangle;
+//   * spheres are bounded with the cone / swept-ball tests of mrt_cull_common.h, triangles with SCREEN-SPACE
+//     EDGE FUNCTIONS.  For a triangle (plane n, k; edge planes m_i, c_i) and a ray o + t d accepted by the
+//     exact test (t > 0), e_i(p) = (w_i . d) / (n . d) with w_i = (m_i.o - c_i) n + (k - n.o) m_i, and
+//     sign(n.d) = sign(k - n.o); w_i . d is affine in the pixel coordinates, so its maximum over the tile is
+//     its value at the tile centre plus a constant.  If that maximum is below a margin for one edge, no ray
+//     of the tile can pass that edge test and the triangle is skipped.  The functions depend on the camera:
+//     the launcher computes them in double for every render (small_primary_functions) and they travel in the
+//     kernel arguments.  The same construction bounds shadow rays: e_i at the point where the shadow ray of
+//     hit point p meets the plane is affine in p, for directional and for point lights, and is bounded over
+//     the ball around the tile's hit points; these functions depend on scene and lights only and are built
+//     at upload (mrt_api.cpp, shadow_functions);
 //   * u = col / W and v = row / H come from two tables computed once per frame size with the same IEEE
 //     division (uv_table_kernel) instead of 1 + P divisions per lane.
+//
+// Culling never changes a result: every comparison carries a margin of 1e-4 of the magnitudes involved
+// (the exact tests round at 6e-8), NaN never culls, and tests/test_gpu_parity.py compares the buffers bit
+// for bit with the brute-force kernel and the oracle.
 //
 // Reference semantics: src/main.cu:60-104,122-157 (render / color_ray with MAX_RECURSION_DEPTH = 0),
 // core/sphere.cuh:32-73, core/triangle.cuh:77-103, core/light.cuh:135-178, core/material.cuh:63-75,134-158.
@@ -57,14 +71,27 @@ __device__ __forceinline__ float wave_max_dpp(float x)
   return bcast(x, 63);
 }
 
+constexpr int SH_STRIDE = 3 * 7 + 2; // floats per (light, triangle): 3 edges x (gx, gy, gz, off, gn, a, b) + sign guard
+
 template <int P> struct VecOf;
 template <> struct VecOf<1> { using f = float; using i = int; };
 template <> struct VecOf<2> { using f = float2; using i = int2; };
 template <> struct VecOf<4> { using f = float4; using i = int4; };
 
+__device__ __forceinline__ float abs1(float x, float y, float z) { return fabsf(x) + fabsf(y) + fabsf(z); }
+
+// Kernel arguments: the common ones plus the primary-ray functions of the triangles, [function][triangle]:
+// 4 functions (3 edges + plane side) x (W0', Wh, Wv); "W0' + um Wh + vm Wv < 0" at the tile centre (um, vm)
+// means that no ray of the padded tile passes that test.
+struct SmallArgs {
+  RenderArgs A;
+  float pri[12][64];
+};
+
 template <int P>
-__global__ __launch_bounds__(256) void render_small_kernel(RenderArgs A)
+__global__ __launch_bounds__(256) void render_small_kernel(SmallArgs S)
 {
+  const RenderArgs &A = S.A;
   const DevScene &sc = A.sc;
   const DevCamera &cam = A.cam;
   const int lane = threadIdx.x & 63;
@@ -87,9 +114,9 @@ __global__ __launch_bounds__(256) void render_small_kernel(RenderArgs A)
   // ---- cone around the tile's rays, padded by one pixel on every side (covers the 121-spp offsets): every
   //      ray of the padded tile is the centre ray plus an offset of norm <= cone_ext (launcher) ----
   float cax, cay, caz, cosT, sinT;
+  const float rw = fast_rcp(float(A.W)), rh = fast_rcp(float(A.H)); // bound arithmetic: approximate is fine
+  const float um = (float(tile_x * TW) + 0.5f * float(TW - 1)) * rw, vm = (float(grow0) + 3.5f) * rh;
   {
-    const float rw = fast_rcp(float(A.W)), rh = fast_rcp(float(A.H)); // bound arithmetic: approximate is fine
-    const float um = (float(tile_x * TW) + 0.5f * float(TW - 1)) * rw, vm = (float(grow0) + 3.5f) * rh;
     cax = ((cam.ux + um * cam.hx) + vm * cam.vx) - cam.ox;
     cay = ((cam.uy + um * cam.hy) + vm * cam.vy) - cam.oy;
     caz = ((cam.uz + um * cam.hz) + vm * cam.vz) - cam.oz;
@@ -125,8 +152,13 @@ __global__ __launch_bounds__(256) void render_small_kernel(RenderArgs A)
     pobj = sc.tri_obj[k];
     g0 = sc.tri[k]; g1 = sc.tri[nt + k]; g2 = sc.tri[2 * nt + k];
     e0 = sc.tri[3 * nt + k] - dot3(cam.ox, cam.oy, cam.oz, g0, g1, g2);
-    pass_primary = ball_may_touch_cone(bx - cam.ox, by - cam.oy, bz - cam.oz, brad * CULL_REL + CULL_ABS, cax, cay, caz,
-                                       cosT, sinT);
+    bool cull = false;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float f = __builtin_fmaf(um, S.pri[3 * i + 1][k], __builtin_fmaf(vm, S.pri[3 * i + 2][k], S.pri[3 * i][k]));
+      cull |= (f < 0.0f); // NaN compares false: never culls
+    }
+    pass_primary = !cull;
   }
   const unsigned long long smask_all = ns >= 64 ? ~0ull : ((1ull << ns) - 1ull);
   const unsigned long long primary_mask = __ballot(pass_primary);
@@ -297,6 +329,7 @@ __global__ __launch_bounds__(256) void render_small_kernel(RenderArgs A)
         Lm2 = Lm * Lm;
       }
       const float reff_shadow = own_s ? sphere_cull_radius(rr, Lm2) : brad;
+      const float Pmax = abs1(B.mx, B.my, B.mz) + B.rho; // >= |hit point|_inf
 
       for (int li = 0; li < sc.nl; ++li) {
         const int lkind = sc.light_kind[li];
@@ -338,7 +371,24 @@ __global__ __launch_bounds__(256) void render_small_kernel(RenderArgs A)
 
         if (__any(any_open)) {
           // which primitives can touch one of the tile's shadow rays (interval [1e-3, t_light], core/light.cuh:28-33)
-          const bool pass = (own_s || own_t) && bundle_may_touch(B, bx, by, bz, reff_shadow);
+          bool pass = (own_s || own_t) && bundle_may_touch(B, bx, by, bz, reff_shadow);
+          if (own_t && pass && li < sc.nls) {
+            // shadow functions of (light li, this triangle), built at upload: [light][23][triangle]
+            const float *fn = sc.tri_shfn + (size_t)li * SH_STRIDE * nt + (lane - ns);
+            auto F = [&](int f) { return fn[(size_t)f * nt]; };
+            const float scale = lkind == 0 ? 1.0f : abs1(lvx, lvy, lvz) + Pmax;
+            bool cull = false;
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+              const float h = __builtin_fmaf(F(7 * i), B.mx, __builtin_fmaf(F(7 * i + 1), B.my,
+                              __builtin_fmaf(F(7 * i + 2), B.mz, F(7 * i + 3))));
+              const float margin = scale * __builtin_fmaf(F(7 * i + 6), Pmax, F(7 * i + 5));
+              cull |= (__builtin_fmaf(B.rho, F(7 * i + 4), h) + margin < 0.0f); // NaN never culls
+            }
+            // point light (almost) in the triangle's plane: the sign argument of the functions fails
+            const bool sign_ok = F(21) > F(22) * Pmax;
+            if (cull && sign_ok) pass = false;
+          }
           const unsigned long long shadow_mask = __ballot(pass);
           n_clusters++; n_exact += __popcll(shadow_mask);
           unsigned long long mask = shadow_mask & smask_all;
@@ -482,26 +532,83 @@ __global__ __launch_bounds__(256) void render_small_kernel(RenderArgs A)
   }
 }
 
-template <int P>
-static hipError_t launch_small(RenderArgs &A, hipStream_t stream)
+// ---- primary-ray functions (host, double; per render) ---------------------------------------------------
+// For triangle j (16 floats at tri16 + 16 j) and an accepted ray, sign(n.d) = sign(num) = s with
+// num = k - n.o as the kernels compute it in fp32, and e_i(p) |n.d| = s w_i . d.  d(u, v) = base + u h + v vv
+// is affine, so over the padded tile around (um, vm):  max s w_i . d = s w_i . d(um, vm) + |Wh| hu + |Wv| hv.
+// Stored: W0' = s w_i . base + that extent + margin, Wh, Wv.  Margin: e_i > -1e-6 is the exact test, and the
+// fp32 rounding of the exact test and of the function's evaluation stay below 1e-4 of the magnitudes in K.
+static void small_primary_functions(const RenderArgs &A, const float *tri16, int nt, double hu, double hv, double dmax,
+                                    float (*pri)[64])
 {
-  // largest offset of a ray of the padded tile (pixels -1..8P horizontally, -1..8 vertically) from the tile's
-  // centre ray, in double, rounded up
+  const double o[3] = {A.cam.ox, A.cam.oy, A.cam.oz};
+  const double h[3] = {A.cam.hx, A.cam.hy, A.cam.hz}, vv[3] = {A.cam.vx, A.cam.vy, A.cam.vz};
+  const double base[3] = {(double)A.cam.ux - o[0], (double)A.cam.uy - o[1], (double)A.cam.uz - o[2]};
+  auto dot = [](const double *a, const double *b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; };
+  auto n1f = [](const double *a) { return std::fabs(a[0]) + std::fabs(a[1]) + std::fabs(a[2]); };
+  const double o1 = n1f(o);
+  for (int j = 0; j < nt; ++j) {
+    const float *q = tri16 + 16 * j;
+    const double n[3] = {q[0], q[1], q[2]}, kp = q[3];
+    // the sign the kernel sees: same fp32 expression as the exact test's numerator
+    const float numf = q[3] - (A.cam.ox * q[0] + (A.cam.oy * q[1] + A.cam.oz * q[2]));
+    const double s = numf >= 0.0f ? 1.0 : -1.0;
+    const double num = kp - dot(n, o), nn1 = n1f(n);
+    for (int i = 0; i < 4; ++i) {
+      double w[3], K;
+      if (i < 3) {
+        const double m[3] = {q[4 + 4 * i], q[5 + 4 * i], q[6 + 4 * i]}, c = q[7 + 4 * i];
+        const double Ai = dot(m, o) - c, m1 = n1f(m);
+        for (int a = 0; a < 3; ++a) w[a] = s * (Ai * n[a] + num * m[a]);
+        K = 1e-6 * nn1 + 1e-4 * ((m1 * o1 + std::fabs(c)) * nn1 + (std::fabs(num) + std::fabs((double)numf)) * m1);
+      } else { // plane side: s (n . d) < 0 on the whole tile means t < 0 for every ray
+        for (int a = 0; a < 3; ++a) w[a] = s * n[a];
+        K = 1e-5 * nn1;
+      }
+      const double Wh = dot(w, h), Wv = dot(w, vv), W0 = dot(w, base);
+      const double ext = std::fabs(Wh) * hu + std::fabs(Wv) * hv;
+      const double W0p = W0 + ext + dmax * K + 1e-6 * (std::fabs(W0) + ext); // the last term: float rounding below
+      pri[3 * i + 0][j] = (float)W0p;
+      pri[3 * i + 1][j] = (float)Wh;
+      pri[3 * i + 2][j] = (float)Wv;
+    }
+  }
+}
+
+template <int P>
+static hipError_t launch_small(const RenderArgs &in, const float *host_tri16, hipStream_t stream)
+{
+  SmallArgs S; // 3.5 KB of kernel arguments
+  S.A = in;
+  RenderArgs &A = S.A;
+  // the padded tile (pixels -1..8P horizontally, -1..8 vertically) around its centre, in u / v units
+  const double hw = (4.0 * P + 0.5) / A.W, hh = 4.5 / A.H;
+  double dmax = 0;
   {
-    const double hw = (4.0 * P + 0.5) / A.W, hh = 4.5 / A.H;
+    // largest offset of a ray of the padded tile from the tile's centre ray, in double, rounded up
     const double hx[3] = {hw * A.cam.hx, hw * A.cam.hy, hw * A.cam.hz};
     const double hy[3] = {hh * A.cam.vx, hh * A.cam.vy, hh * A.cam.vz};
     double p = 0, m = 0;
     for (int k = 0; k < 3; ++k) { p += (hx[k] + hy[k]) * (hx[k] + hy[k]); m += (hx[k] - hy[k]) * (hx[k] - hy[k]); }
     A.cone_ext = float(std::sqrt(p > m ? p : m) * 1.001);
+    // largest 1-norm of a ray direction over the padded frame: |d|_1 is convex in (u, v), so at a corner
+    for (int c = 0; c < 4; ++c) {
+      const double u = (c & 1) ? 1.0 + hw : -hw, v = (c & 2) ? 1.0 + hh : -hh;
+      const double d1 = std::fabs(A.cam.ux + u * A.cam.hx + v * A.cam.vx - A.cam.ox) +
+                        std::fabs(A.cam.uy + u * A.cam.hy + v * A.cam.vy - A.cam.oy) +
+                        std::fabs(A.cam.uz + u * A.cam.hz + v * A.cam.vz - A.cam.oz);
+      if (!(d1 <= dmax)) dmax = d1; // a NaN camera gives NaN functions, which never cull
+    }
+    dmax *= 1.001;
   }
+  small_primary_functions(A, host_tri16, A.sc.nt, hw * 1.0001, hh * 1.0001, dmax, S.pri);
   // vector stores need every lane's first pixel on a 4P-byte boundary in all three buffers
   const uintptr_t align = 4 * P - 1;
   A.wide = (A.W % P == 0) && ((uintptr_t)A.rgb & align) == 0 && ((uintptr_t)A.id & align) == 0 &&
            ((uintptr_t)A.t & align) == 0;
   const int tiles_x = (A.W + 8 * P - 1) / (8 * P), tiles_y = (A.local_rows + 7) / 8;
   if (tiles_x == 0 || tiles_y == 0) return hipSuccess;
-  hipLaunchKernelGGL(render_small_kernel<P>, dim3((tiles_x + 3) / 4, tiles_y), dim3(256), 0, stream, A);
+  hipLaunchKernelGGL(render_small_kernel<P>, dim3((tiles_x + 3) / 4, tiles_y), dim3(256), 0, stream, S);
   return hipGetLastError();
 }
 
@@ -515,14 +622,13 @@ int small_pixels_per_lane()
   return v;
 }
 
-hipError_t launch_render_small(const RenderArgs &in, hipStream_t stream)
+hipError_t launch_render_small(const RenderArgs &A, const float *host_tri16, hipStream_t stream)
 {
-  RenderArgs A = in;
-  if (A.sc.ns + A.sc.nt > 64 || !A.utab || !A.vtab) return hipErrorInvalidValue;
+  if (A.sc.ns + A.sc.nt > 64 || !A.utab || !A.vtab || (A.sc.nt > 0 && !host_tri16)) return hipErrorInvalidValue;
   switch (small_pixels_per_lane()) {
-  case 1: return launch_small<1>(A, stream);
-  case 4: return launch_small<4>(A, stream);
-  default: return launch_small<2>(A, stream);
+  case 1: return launch_small<1>(A, host_tri16, stream);
+  case 4: return launch_small<4>(A, host_tri16, stream);
+  default: return launch_small<2>(A, host_tri16, stream);
   }
 }
 

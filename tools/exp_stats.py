@@ -3,7 +3,7 @@ import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from raytracing_amd import capi, scenes
 cfgs = sys.argv[1].split(",")
-ctx = capi.Context(0); ctx.set_cull(2)
+ctx = capi.Context(0); ctx.set_cull(int(sys.argv[2]) if len(sys.argv) > 2 else 2)
 for cfg in cfgs:
     if cfg == "C2":
         flat, cam = scenes.default_scene(); W, H = 1920, 1080
