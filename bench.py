@@ -207,6 +207,17 @@ def main():
         alg_flops = my_rays * flops_ray
         ach_gbs = alg_bytes / (kern_ms * 1e-3) / 1e9
         ach_tf = alg_flops / (kern_ms * 1e-3) / 1e12
+        small = flat.num_spheres + flat.num_triangles <= 64
+        if not fr.ctx.cull:
+            kernel_name, kernel_desc = "render_kernel", "render_kernel (brute force: every ray x every primitive)"
+        elif small:
+            kernel_name = "render_small_kernel"
+            kernel_desc = ("render_small_kernel: 16x8-pixel tiles, 2 pixels per lane, per-tile culling (cone test for "
+                           "spheres, screen-space edge functions for triangles) + exact tests")
+        else:
+            kernel_name = "render_cull_kernel"
+            kernel_desc = ("render_cull_kernel: per-tile conservative culling over the Morton-ordered primitive "
+                           "hierarchy + exact tests")
         out = {
             "metric": "Mrays/s (primary+shadow) at 1920x1080" if args.config in ("C2", "C5") else
                       "Mrays/s (primary+shadow) at 3840x2160",
@@ -218,12 +229,11 @@ def main():
                        "parallelism": f"{world} GPU(s): 8-row strips round-robin, scene replicated" +
                                       ("" if world == 1 else ", RCCL gather to rank 0 + strip assembly"),
                        "outputs": "rgb f32 + id i32 + t f32" if not args.no_ids else "rgb f32",
-                       "kernel": "render_cull_kernel: per-tile conservative culling over the Morton-ordered primitive hierarchy + exact tests" if fr.ctx.cull else
-                                 "render_kernel (brute force)"},
+                       "kernel": kernel_desc},
             "roofline": {"bound": "hbm", "achieved": round(ach_gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(ach_gbs / HBM_PEAK_GBS, 5),
                          "traffic": measured_traffic(args.config, alg_bytes) if world == 1 else None,
-                         "kernel": "render_cull_kernel" if fr.ctx.cull else "render_kernel", "kernel_ms": round(kern_ms, 5),
+                         "kernel": kernel_name, "kernel_ms": round(kern_ms, 5),
                          "algorithmic_bytes_per_launch": alg_bytes},
             "roofline_valu": {"bound": "fp32 vector ALU (no MFMA: no dense contraction)",
                               "achieved": round(ach_tf, 4), "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s",

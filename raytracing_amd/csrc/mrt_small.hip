@@ -37,6 +37,7 @@
 
 #include <cmath>
 #include <cstdlib>
+#include <type_traits>
 
 namespace mrt {
 
@@ -88,8 +89,8 @@ struct SmallArgs {
   float pri[12][64];
 };
 
-template <int P>
-__global__ __launch_bounds__(256) void render_small_kernel(SmallArgs S)
+template <int P, bool MULTI>
+__device__ __forceinline__ void render_small_body(const SmallArgs &S)
 {
   const RenderArgs &A = S.A;
   const DevScene &sc = A.sc;
@@ -175,7 +176,7 @@ __global__ __launch_bounds__(256) void render_small_kernel(SmallArgs S)
   }
   unsigned int n_shadow = 0, n_hit = 0, n_occl = 0;
   unsigned int n_exact = 0, n_clusters = 0; // wave-uniform diagnostics (lane 0 reports them)
-  const int nsamp = A.spp;
+  const int nsamp = MULTI ? A.spp : 1; // MULTI = false: one sample, no accumulation across samples
   const float DIVW = 13.0f, DIVH = 13.0f;
 
   // u, v of the lane's pixels: tables hold float(i) / float(W) and float(i) / float(H) (uv_table_kernel)
@@ -331,28 +332,28 @@ __global__ __launch_bounds__(256) void render_small_kernel(SmallArgs S)
       const float reff_shadow = own_s ? sphere_cull_radius(rr, Lm2) : brad;
       const float Pmax = abs1(B.mx, B.my, B.mz) + B.rho; // >= |hit point|_inf
 
-      for (int li = 0; li < sc.nl; ++li) {
-        const int lkind = sc.light_kind[li];
-        const float lvx = sc.light_vec[3 * li], lvy = sc.light_vec[3 * li + 1], lvz = sc.light_vec[3 * li + 2];
-        // per-pixel shadow ray and the light's "hit record" (ray_from: core/light.cuh:73-81 / :47-53)
-        float sdx[P], sdy[P], sdz[P], lnx[P], lny[P], lnz[P], sa[P];
+      // One light.  POINT is a compile-time switch: for a directional light the shadow ray direction, its
+      // squared length and the light's normal are wave-uniform scalars, for a point light per-pixel registers.
+      auto shade_light = [&](auto point_tag, int li, float lvx, float lvy, float lvz) {
+        constexpr bool POINT = decltype(point_tag)::value;
+        constexpr int Q = POINT ? P : 1;
+        auto ix = [](int p) { return POINT ? p : 0; };
+        // shadow ray and the light's "hit record" (ray_from: core/light.cuh:73-81 / :47-53)
+        float sdx[Q], sdy[Q], sdz[Q], lnx[Q], lny[Q], lnz[Q], sa[Q];
         float tl;
         bool need[P], open[P], any_open = false;
-        if (lkind == 0) {
+        if (!POINT) {
           tl = MRT_INF;
           B.point = false;
           B.Dx = -lvx; B.Dy = -lvy; B.Dz = -lvz;
-#pragma unroll
-          for (int p = 0; p < P; ++p) {
-            sdx[p] = -lvx; sdy[p] = -lvy; sdz[p] = -lvz;
-            lnx[p] = lvx; lny[p] = lvy; lnz[p] = lvz;
-          }
+          sdx[0] = -lvx; sdy[0] = -lvy; sdz[0] = -lvz;
+          lnx[0] = lvx; lny[0] = lvy; lnz[0] = lvz;
         } else {
           tl = 1.0f;
           B.point = true;
           B.Dx = lvx - B.mx; B.Dy = lvy - B.my; B.Dz = lvz - B.mz;
 #pragma unroll
-          for (int p = 0; p < P; ++p) {
+          for (int p = 0; p < Q; ++p) {
             sdx[p] = lvx - hpx[p]; sdy[p] = lvy - hpy[p]; sdz[p] = lvz - hpz[p];
             float nx = hpx[p] - lvx, ny = hpy[p] - lvy, nz = hpz[p] - lvz;
             normalize3(nx, ny, nz);
@@ -361,14 +362,14 @@ __global__ __launch_bounds__(256) void render_small_kernel(SmallArgs S)
         }
         B.DD = dot3(B.Dx, B.Dy, B.Dz, B.Dx, B.Dy, B.Dz);
 #pragma unroll
+        for (int q = 0; q < Q; ++q) sa[q] = dot3(sdx[q], sdy[q], sdz[q], sdx[q], sdy[q], sdz[q]);
+#pragma unroll
         for (int p = 0; p < P; ++p) {
-          sa[p] = dot3(sdx[p], sdy[p], sdz[p], sdx[p], sdy[p], sdz[p]);
           // the light must not shine through the surface, core/light.cuh:148
-          need[p] = have_hit[p] && !(dot3(sdx[p], sdy[p], sdz[p], hnx[p], hny[p], hnz[p]) < 0);
+          need[p] = have_hit[p] && !(dot3(sdx[ix(p)], sdy[ix(p)], sdz[ix(p)], hnx[p], hny[p], hnz[p]) < 0);
           open[p] = need[p];
           any_open |= open[p];
         }
-
         if (__any(any_open)) {
           // which primitives can touch one of the tile's shadow rays (interval [1e-3, t_light], core/light.cuh:28-33)
           bool pass = (own_s || own_t) && bundle_may_touch(B, bx, by, bz, reff_shadow);
@@ -376,7 +377,7 @@ __global__ __launch_bounds__(256) void render_small_kernel(SmallArgs S)
             // shadow functions of (light li, this triangle), built at upload: [light][23][triangle]
             const float *fn = sc.tri_shfn + (size_t)li * SH_STRIDE * nt + (lane - ns);
             auto F = [&](int f) { return fn[(size_t)f * nt]; };
-            const float scale = lkind == 0 ? 1.0f : abs1(lvx, lvy, lvz) + Pmax;
+            const float scale = POINT ? abs1(lvx, lvy, lvz) + Pmax : 1.0f;
             bool cull = false;
 #pragma unroll
             for (int i = 0; i < 3; ++i) {
@@ -401,12 +402,12 @@ __global__ __launch_bounds__(256) void render_small_kernel(SmallArgs S)
 #pragma unroll
             for (int p = 0; p < P; ++p) {
               const float ocx = hpx[p] - scx, ocy = hpy[p] - scy, ocz = hpz[p] - scz;
-              const float b = dot3(ocx, ocy, ocz, sdx[p], sdy[p], sdz[p]);
+              const float b = dot3(ocx, ocy, ocz, sdx[ix(p)], sdy[ix(p)], sdz[ix(p)]);
               const float c = dot3(ocx, ocy, ocz, ocx, ocy, ocz) - srr;
-              const float disc = b * b - sa[p] * c;
+              const float disc = b * b - sa[ix(p)] * c;
               if (open[p] && disc >= 0.0f) {
                 float t;
-                if (sphere_roots(sa[p], b, disc, 1e-3f, tl, t)) open[p] = false;
+                if (sphere_roots(sa[ix(p)], b, disc, 1e-3f, tl, t)) open[p] = false;
               }
               still |= open[p];
             }
@@ -421,9 +422,9 @@ __global__ __launch_bounds__(256) void render_small_kernel(SmallArgs S)
             bool still = false;
 #pragma unroll
             for (int p = 0; p < P; ++p) {
-              const float rdn = dot3(sdx[p], sdy[p], sdz[p], pnx, pny, pnz);
+              const float rdn = dot3(sdx[ix(p)], sdy[ix(p)], sdz[ix(p)], pnx, pny, pnz);
               const float t = (kp - dot3(hpx[p], hpy[p], hpz[p], pnx, pny, pnz)) / rdn;
-              const float px = hpx[p] + t * sdx[p], py = hpy[p] + t * sdy[p], pz = hpz[p] + t * sdz[p];
+              const float px = hpx[p] + t * sdx[ix(p)], py = hpy[p] + t * sdy[ix(p)], pz = hpz[p] + t * sdz[ix(p)];
               const float d0 = dot3(q[4], q[5], q[6], px, py, pz) - q[7];
               const float d1 = dot3(q[8], q[9], q[10], px, py, pz) - q[11];
               const float d2 = dot3(q[12], q[13], q[14], px, py, pz) - q[15];
@@ -441,7 +442,7 @@ __global__ __launch_bounds__(256) void render_small_kernel(SmallArgs S)
           if (need[p] && valid[p]) { n_shadow++; if (!open[p]) n_occl++; }
           if (open[p]) {
             // light_bounce with the LIGHT's normal, as the reference passes it (core/light.cuh:164-168)
-            const float dn = dot3(sdx[p], sdy[p], sdz[p], lnx[p], lny[p], lnz[p]);
+            const float dn = dot3(sdx[ix(p)], sdy[ix(p)], sdz[ix(p)], lnx[ix(p)], lny[ix(p)], lnz[ix(p)]);
             float cr, cg, cb;
             if (sc.mat_kind[best_obj[p]] == 0) { // DiffuseMaterial::light_bounce, core/material.cuh:63-75
               const float scale = -dn;
@@ -449,7 +450,7 @@ __global__ __launch_bounds__(256) void render_small_kernel(SmallArgs S)
               else { cr = 0.0f; cg = 0.0f; cb = 0.0f; }
             } else {                              // MetallicMaterial::light_bounce, core/material.cuh:134-158
               const float s2 = 2.0f * dn;
-              const float rx = sdx[p] - s2 * lnx[p], ry = sdy[p] - s2 * lny[p], rz = sdz[p] - s2 * lnz[p];
+              const float rx = sdx[ix(p)] - s2 * lnx[ix(p)], ry = sdy[ix(p)] - s2 * lny[ix(p)], rz = sdz[ix(p)] - s2 * lnz[ix(p)];
               if (dot3(rx, ry, rz, dx[p], dy[p], dz[p]) < -0.99f) { cr = lcr; cg = lcg; cb = lcb; }
               else { cr = 0.001f; cg = 0.001f; cb = 0.001f; }
             }
@@ -457,6 +458,11 @@ __global__ __launch_bounds__(256) void render_small_kernel(SmallArgs S)
             else { lr[p] = cr; lg[p] = cg; lb[p] = cb; have_light[p] = true; }
           }
         }
+      };
+      for (int li = 0; li < sc.nl; ++li) {
+        const float lvx = sc.light_vec[3 * li], lvy = sc.light_vec[3 * li + 1], lvz = sc.light_vec[3 * li + 2];
+        if (sc.light_kind[li] == 0) shade_light(std::false_type{}, li, lvx, lvy, lvz);
+        else shade_light(std::true_type{}, li, lvx, lvy, lvz);
       }
     }
 
@@ -531,6 +537,12 @@ __global__ __launch_bounds__(256) void render_small_kernel(SmallArgs S)
     }
   }
 }
+
+// Two pixels per lane and one sample fit 96 registers (five waves per SIMD) without spilling when asked to;
+// left alone the compiler takes 100 and loses a wave (measured: 23.2 -> 22.0 us on the default frame).
+template <int P, bool MULTI>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(P == 2 && !MULTI ? 5 : 1, 8)))
+void render_small_kernel(SmallArgs S) { render_small_body<P, MULTI>(S); }
 
 // ---- primary-ray functions (host, double; per render) ---------------------------------------------------
 // For triangle j (16 floats at tri16 + 16 j) and an accepted ray, sign(n.d) = sign(num) = s with
@@ -608,7 +620,9 @@ static hipError_t launch_small(const RenderArgs &in, const float *host_tri16, hi
            ((uintptr_t)A.t & align) == 0;
   const int tiles_x = (A.W + 8 * P - 1) / (8 * P), tiles_y = (A.local_rows + 7) / 8;
   if (tiles_x == 0 || tiles_y == 0) return hipSuccess;
-  hipLaunchKernelGGL(render_small_kernel<P>, dim3((tiles_x + 3) / 4, tiles_y), dim3(256), 0, stream, S);
+  const dim3 grid((tiles_x + 3) / 4, tiles_y);
+  if (A.spp > 1) hipLaunchKernelGGL((render_small_kernel<P, true>), grid, dim3(256), 0, stream, S);
+  else hipLaunchKernelGGL((render_small_kernel<P, false>), grid, dim3(256), 0, stream, S);
   return hipGetLastError();
 }
 

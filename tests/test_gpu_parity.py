@@ -400,6 +400,61 @@ def test_random_scenes_both_kernels_vs_oracle(gpu_ctx, seed):
     assert_stats_parity(g["stats"], r["stats"])
 
 
+def _random_small_scene(seed):
+    """At most 64 primitives (the small-scene kernel's range), built to stress its screen-space and shadow
+    edge functions: coplanar quads (two triangles sharing a hypotenuse), slivers, triangles behind and
+    around the camera, a camera ON a triangle's plane (numerator k - n.o = 0), point lights in a triangle's
+    plane, at a vertex and inside a sphere, up to 6 lights (the functions cover the first 4)."""
+    rng = np.random.default_rng(1000 + seed)
+    ns, nq, nt = int(rng.integers(0, 20)), int(rng.integers(0, 8)), int(rng.integers(1, 24))
+    c = rng.uniform(-15, 15, (ns, 3))
+    r = 10.0 ** rng.uniform(-2, 1.0, ns)
+    sp = np.concatenate([c, r[:, None]], axis=1).astype(np.float32) if ns else np.zeros((0, 4), np.float32)
+    tris = []
+    for _ in range(nq):  # quads: p, p+e1, p+e1+e2 / p, p+e1+e2, p+e2
+        p0 = rng.uniform(-15, 15, 3); e1 = rng.normal(size=3) * 10.0 ** rng.uniform(-1, 1.2)
+        e2 = np.cross(e1, rng.normal(size=3)); e2 *= 10.0 ** rng.uniform(-1, 1.2) / (np.linalg.norm(e2) + 1e-9)
+        tris += [[p0, p0 + e1, p0 + e1 + e2], [p0, p0 + e1 + e2, p0 + e2]]
+    a = rng.uniform(-15, 15, (nt, 3))
+    size = 10.0 ** rng.uniform(-2, 1.5, (nt, 1))
+    free = np.stack([a, a + rng.normal(size=(nt, 3)) * size, a + rng.normal(size=(nt, 3)) * size], axis=1)
+    free[1::5, 2] = free[1::5, 1] + 1e-4 * rng.normal(size=free[1::5, 1].shape)  # slivers
+    tv = np.concatenate([np.asarray(tris, np.float64).reshape(-1, 3, 3), free]).astype(np.float32)
+    look_from = rng.uniform(-12, 12, 3)
+    if seed % 3 == 0:  # camera in the plane of triangle 0
+        w = rng.uniform(0.2, 0.6, 3); w /= w.sum()
+        look_from = (tv[0].astype(np.float64) * w[:, None]).sum(0) + (tv[0, 1] - tv[0, 0]) * 3.0
+    n = ns + len(tv)
+    order = rng.permutation(n)
+    sphere_obj, tri_obj = np.sort(order[:ns]), np.sort(order[ns:])
+    kind, rgb = scenes._cycle_materials(n)
+    t1 = tv[len(tv) // 2].astype(np.float64)
+    lights = [(capi.LIGHT_DIRECTIONAL, tuple(rng.normal(size=3)), (3.0, 2.0, 1.0)),
+              (capi.LIGHT_POINT, tuple(t1.mean(0) + 2.5 * (t1[1] - t1[0])), (0.5, 0.7, 0.9)),  # in a triangle's plane
+              (capi.LIGHT_POINT, tuple(tv[-1, 0]), (0.4, 0.4, 0.4)),                           # at a vertex
+              (capi.LIGHT_DIRECTIONAL, tuple(np.cross(t1[1] - t1[0], t1[2] - t1[0]) + 1e-3), (0.3, 0.3, 0.3)),
+              (capi.LIGHT_POINT, tuple(rng.uniform(-12, 12, 3)), (0.6, 0.6, 0.6)),
+              (capi.LIGHT_POINT, tuple(c[0]) if ns else (1.0, 2.0, 3.0), (1.0, 1.0, 1.0))][:1 + seed % 6]
+    cam = {"look_from": tuple(look_from), "look_at": tuple(rng.uniform(-4, 4, 3)), "up": (0.1, 1.0, 0.05),
+           "vfov": float(rng.uniform(15, 110))}
+    return scenes.SceneSpec(f"small{seed}", sp, sphere_obj, tv, tri_obj, kind, rgb, lights, cam)
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_random_small_scenes_vs_oracle(gpu_ctx, seed):
+    spec = _random_small_scene(seed)
+    flat = spec.flatten()
+    assert flat.num_spheres + flat.num_triangles <= 64
+    gpu_ctx.upload(flat)
+    W, H = (136, 104) if seed % 4 else (200, 72)   # 200 is a multiple of 4 and 8: vector stores; 136 of 8 only
+    cam = spec.cam12(W / H)
+    spp = 121 if seed == 5 else 1
+    g = gpu_ctx.render(cam, W, H, spp=spp)
+    r = O.Scene.from_spec(spec).render(cam, W, H, spp=spp, nthreads=8)
+    assert_frame_parity(g, r, spec.name)
+    assert_stats_parity(g["stats"], r["stats"])
+
+
 # ------------------------------------------------------------------ strips (multi-GPU partition on one GPU)
 
 @pytest.mark.parametrize("nranks,strip", [(2, 8), (3, 8), (8, 8), (4, 16)])
