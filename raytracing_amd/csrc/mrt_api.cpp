@@ -41,7 +41,8 @@ struct mrt_ctx {
   int uv_w = 0, uv_h = 0, uv_nu = 0;
   // host copy of the triangles of a small scene (16 floats each, device order): the small-scene kernel's
   // launcher derives the camera-dependent culling functions from it for every render
-  std::vector<float> small_tri16;
+  std::vector<float> small_tri16, small_sph;
+  std::vector<int32_t> small_tri_obj, small_sph_obj;
 };
 
 static thread_local std::string g_create_err;
@@ -116,7 +117,11 @@ static hipError_t launch_by_mode(mrt_ctx *ctx, mrt::RenderArgs &A, hipStream_t s
     hipError_t e = ensure_uv_tables(ctx, A.W, A.H, st);
     if (e != hipSuccess) return e;
     A.utab = ctx->uv_mem; A.vtab = ctx->uv_mem + ctx->uv_nu;
-    return mrt::launch_render_small(A, ctx->small_tri16.data(), st);
+    mrt::SmallHost hs;
+    hs.ns = (int)ctx->small_sph_obj.size(); hs.nt = (int)ctx->small_tri_obj.size();
+    hs.sph = ctx->small_sph.data(); hs.sph_obj = ctx->small_sph_obj.data();
+    hs.tri16 = ctx->small_tri16.data(); hs.tri_obj = ctx->small_tri_obj.data();
+    return mrt::launch_render_small(A, hs, st);
   }
   }
 }
@@ -470,6 +475,14 @@ int mrt_scene_upload(mrt_ctx *ctx, const mrt_scene_desc *s)
       cx[i] = s->sphere_cx[g]; cy[i] = s->sphere_cy[g]; cz[i] = s->sphere_cz[g]; r[i] = s->sphere_r[g];
       so[i] = s->sphere_obj[g];
     }
+    try {
+      ctx->small_sph.clear(); ctx->small_sph_obj.clear();
+      if (ns + nt <= 64)
+        for (size_t i = 0; i < ns; ++i) {
+          ctx->small_sph.insert(ctx->small_sph.end(), {cx[i], cy[i], cz[i], r[i]});
+          ctx->small_sph_obj.push_back(so[i]);
+        }
+    } catch (...) { return fail(ctx, MRT_ERR_INVALID, "out of host memory"); }
     // a sphere's own ball must contain it even for a negative radius: the hit test only sees r*r
     std::vector<float> rabs(ns);
     for (size_t i = 0; i < ns; ++i) rabs[i] = std::fabs(r[i]);
@@ -503,7 +516,10 @@ int mrt_scene_upload(mrt_ctx *ctx, const mrt_scene_desc *s)
         shadow_functions(rec + 16 * i, s->light_kind[l], s->light_vec + 3 * l, f);
         for (int k = 0; k < SH_STRIDE; ++k) shfn[(l * SH_STRIDE + k) * nt + i] = f[k];
       }
-    try { if (small) ctx->small_tri16.assign(rec, rec + 16 * nt); else ctx->small_tri16.clear(); }
+    try {
+      if (small) { ctx->small_tri16.assign(rec, rec + 16 * nt); ctx->small_tri_obj.assign(to, to + nt); }
+      else { ctx->small_tri16.clear(); ctx->small_tri_obj.clear(); }
+    }
     catch (...) { return fail(ctx, MRT_ERR_INVALID, "out of host memory"); }
     float *ct = (float *)(img.data() + o_ct);
     cluster_bounds(bnd, bnd + nt, bnd + 2 * nt, bnd + 3 * nt, nt, ct);

@@ -77,8 +77,15 @@ hipError_t launch_render_cull(const RenderArgs &args, hipStream_t stream);
 hipError_t launch_render_cull2(const RenderArgs &args, int waves, hipStream_t stream);
 
 // scenes of at most 64 primitives (mrt_small.hip); needs args.utab / args.vtab
-// host_tri16: host copy of the triangles (16 floats each, device order), for the per-render primary functions
-hipError_t launch_render_small(const RenderArgs &args, const float *host_tri16, hipStream_t stream);
+// host copy of a small scene in device order, from which the launcher derives the camera-dependent kernel arguments
+struct SmallHost {
+  int ns = 0, nt = 0;
+  const float *sph = nullptr;       // [ns][4] centre xyz, radius
+  const int32_t *sph_obj = nullptr; // [ns]
+  const float *tri16 = nullptr;     // [nt][16]
+  const int32_t *tri_obj = nullptr; // [nt]
+};
+hipError_t launch_render_small(const RenderArgs &args, const SmallHost &host, hipStream_t stream);
 hipError_t launch_uv_table(float *utab, int nu, int W, float *vtab, int nv, int H, hipStream_t stream);
 
 // launchers (mrt_kernels.hip)

@@ -37,6 +37,7 @@
 
 #include <cmath>
 #include <cstdlib>
+#include <cstring>
 #include <type_traits>
 
 namespace mrt {
@@ -81,13 +82,19 @@ template <> struct VecOf<4> { using f = float4; using i = int4; };
 
 __device__ __forceinline__ float abs1(float x, float y, float z) { return fabsf(x) + fabsf(y) + fabsf(z); }
 
-// Kernel arguments: the common ones plus the primary-ray functions of the triangles, [function][triangle]:
-// 4 functions (3 edges + plane side) x (W0', Wh, Wv); "W0' + um Wh + vm Wv < 0" at the tile centre (um, vm)
-// means that no ray of the padded tile passes that test.
+// Kernel arguments: the common ones plus everything a wave needs about "its" primitives before the first
+// exact test, [field][lane] -- read straight from the argument segment, one memory round trip after launch:
+//   sphere lanes:   0-2 centre - origin, 3 primary cull radius, 4-6 origin - centre, 7 |o - c|^2 - r^2, 8 object
+//   triangle lanes: 0-11 four functions (3 edges + plane side) x (W0', Wh, Wv): "W0' + um Wh + vm Wv < 0" at the
+//                   tile centre (um, vm) means that no ray of the padded tile passes that test;
+//                   12 k - n.o, 13 object
+// The exact-test terms (4-7, 12) are computed on the host with the kernels' fp32 operations in the same order.
+enum { SMALL_FIELDS = 14 };
 struct SmallArgs {
   RenderArgs A;
-  float pri[12][64];
+  float prm[SMALL_FIELDS][64];
 };
+static_assert(sizeof(SmallArgs) <= 4096, "kernel arguments are limited to 4 KB");
 
 template <int P, bool MULTI>
 __device__ __forceinline__ void render_small_body(const SmallArgs &S)
@@ -138,28 +145,27 @@ __device__ __forceinline__ void render_small_body(const SmallArgs &S)
   int pobj = 0;
   bool pass_primary = false;
   if (own_s) {
+    pass_primary = ball_may_touch_cone(S.prm[0][lane], S.prm[1][lane], S.prm[2][lane], S.prm[3][lane], cax, cay, caz,
+                                       cosT, sinT);
+    e0 = S.prm[4][lane]; e1 = S.prm[5][lane]; e2 = S.prm[6][lane]; e3 = S.prm[7][lane];
+    pobj = __float_as_int(S.prm[8][lane]);
+    // for the shadow rays and the hit record (not needed before the first exact test)
     bx = sc.sph_cx[lane]; by = sc.sph_cy[lane]; bz = sc.sph_cz[lane]; brad = sc.sph_r[lane];
-    pobj = sc.sph_obj[lane];
     g0 = bx; g1 = by; g2 = bz;
-    e0 = cam.ox - bx; e1 = cam.oy - by; e2 = cam.oz - bz;
     rr = brad * brad;
-    e3 = dot3(e0, e1, e2, e0, e1, e2) - rr;
-    const float wx = bx - cam.ox, wy = by - cam.oy, wz = bz - cam.oz;
-    const float L2 = dot3(wx, wy, wz, wx, wy, wz);
-    pass_primary = ball_may_touch_cone(wx, wy, wz, sphere_cull_radius(rr, L2), cax, cay, caz, cosT, sinT);
   } else if (own_t) {
     const int k = lane - ns;
-    bx = sc.tri_bx[k]; by = sc.tri_by[k]; bz = sc.tri_bz[k]; brad = sc.tri_br[k];
-    pobj = sc.tri_obj[k];
-    g0 = sc.tri[k]; g1 = sc.tri[nt + k]; g2 = sc.tri[2 * nt + k];
-    e0 = sc.tri[3 * nt + k] - dot3(cam.ox, cam.oy, cam.oz, g0, g1, g2);
     bool cull = false;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const float f = __builtin_fmaf(um, S.pri[3 * i + 1][k], __builtin_fmaf(vm, S.pri[3 * i + 2][k], S.pri[3 * i][k]));
+      const float f = __builtin_fmaf(um, S.prm[3 * i + 1][lane], __builtin_fmaf(vm, S.prm[3 * i + 2][lane], S.prm[3 * i][lane]));
       cull |= (f < 0.0f); // NaN compares false: never culls
     }
     pass_primary = !cull;
+    e0 = S.prm[12][lane];
+    pobj = __float_as_int(S.prm[13][lane]);
+    bx = sc.tri_bx[k]; by = sc.tri_by[k]; bz = sc.tri_bz[k]; brad = sc.tri_br[k];
+    g0 = sc.tri[k]; g1 = sc.tri[nt + k]; g2 = sc.tri[2 * nt + k];
   }
   const unsigned long long smask_all = ns >= 64 ? ~0ull : ((1ull << ns) - 1ull);
   const unsigned long long primary_mask = __ballot(pass_primary);
@@ -550,9 +556,23 @@ void render_small_kernel(SmallArgs S) { render_small_body<P, MULTI>(S); }
 // is affine, so over the padded tile around (um, vm):  max s w_i . d = s w_i . d(um, vm) + |Wh| hu + |Wv| hv.
 // Stored: W0' = s w_i . base + that extent + margin, Wh, Wv.  Margin: e_i > -1e-6 is the exact test, and the
 // fp32 rounding of the exact test and of the function's evaluation stay below 1e-4 of the magnitudes in K.
-static void small_primary_functions(const RenderArgs &A, const float *tri16, int nt, double hu, double hv, double dmax,
-                                    float (*pri)[64])
+static void small_primary_functions(const RenderArgs &A, const SmallHost &hs, double hu, double hv, double dmax,
+                                    float (*prm)[64])
 {
+  const int ns = hs.ns, nt = hs.nt;
+  const float *tri16 = hs.tri16;
+  // spheres: the terms of the exact test (fp32, the kernels' operation order) and the cone-test inputs
+  for (int i = 0; i < ns; ++i) {
+    const float cx = hs.sph[4 * i], cy = hs.sph[4 * i + 1], cz = hs.sph[4 * i + 2], r = hs.sph[4 * i + 3];
+    const float e0 = A.cam.ox - cx, e1 = A.cam.oy - cy, e2 = A.cam.oz - cz, rr = r * r;
+    const float cc = (e0 * e0 + (e1 * e1 + e2 * e2)) - rr;
+    const float wx = cx - A.cam.ox, wy = cy - A.cam.oy, wz = cz - A.cam.oz;
+    const double L2 = (double)wx * wx + (double)wy * wy + (double)wz * wz;
+    prm[0][i] = wx; prm[1][i] = wy; prm[2][i] = wz;
+    prm[3][i] = (float)((std::sqrt((double)rr + 2e-6 * L2) * 1.001 + 1e-6) * (1.0 + 1e-6)); // sphere_cull_radius, rounded up
+    prm[4][i] = e0; prm[5][i] = e1; prm[6][i] = e2; prm[7][i] = cc;
+    std::memcpy(&prm[8][i], &hs.sph_obj[i], 4);
+  }
   const double o[3] = {A.cam.ox, A.cam.oy, A.cam.oz};
   const double h[3] = {A.cam.hx, A.cam.hy, A.cam.hz}, vv[3] = {A.cam.vx, A.cam.vy, A.cam.vz};
   const double base[3] = {(double)A.cam.ux - o[0], (double)A.cam.uy - o[1], (double)A.cam.uz - o[2]};
@@ -561,6 +581,8 @@ static void small_primary_functions(const RenderArgs &A, const float *tri16, int
   const double o1 = n1f(o);
   for (int j = 0; j < nt; ++j) {
     const float *q = tri16 + 16 * j;
+    float (*pri)[64] = prm;
+    const int col = ns + j; // the lane that owns triangle j
     const double n[3] = {q[0], q[1], q[2]}, kp = q[3];
     // the sign the kernel sees: same fp32 expression as the exact test's numerator
     const float numf = q[3] - (A.cam.ox * q[0] + (A.cam.oy * q[1] + A.cam.oz * q[2]));
@@ -580,15 +602,17 @@ static void small_primary_functions(const RenderArgs &A, const float *tri16, int
       const double Wh = dot(w, h), Wv = dot(w, vv), W0 = dot(w, base);
       const double ext = std::fabs(Wh) * hu + std::fabs(Wv) * hv;
       const double W0p = W0 + ext + dmax * K + 1e-6 * (std::fabs(W0) + ext); // the last term: float rounding below
-      pri[3 * i + 0][j] = (float)W0p;
-      pri[3 * i + 1][j] = (float)Wh;
-      pri[3 * i + 2][j] = (float)Wv;
+      pri[3 * i + 0][col] = (float)W0p;
+      pri[3 * i + 1][col] = (float)Wh;
+      pri[3 * i + 2][col] = (float)Wv;
     }
+    prm[12][col] = numf;
+    std::memcpy(&prm[13][col], &hs.tri_obj[j], 4);
   }
 }
 
 template <int P>
-static hipError_t launch_small(const RenderArgs &in, const float *host_tri16, hipStream_t stream)
+static hipError_t launch_small(const RenderArgs &in, const SmallHost &hs, hipStream_t stream)
 {
   SmallArgs S; // 3.5 KB of kernel arguments
   S.A = in;
@@ -613,7 +637,7 @@ static hipError_t launch_small(const RenderArgs &in, const float *host_tri16, hi
     }
     dmax *= 1.001;
   }
-  small_primary_functions(A, host_tri16, A.sc.nt, hw * 1.0001, hh * 1.0001, dmax, S.pri);
+  small_primary_functions(A, hs, hw * 1.0001, hh * 1.0001, dmax, S.prm);
   // vector stores need every lane's first pixel on a 4P-byte boundary in all three buffers
   const uintptr_t align = 4 * P - 1;
   A.wide = (A.W % P == 0) && ((uintptr_t)A.rgb & align) == 0 && ((uintptr_t)A.id & align) == 0 &&
@@ -636,13 +660,13 @@ int small_pixels_per_lane()
   return v;
 }
 
-hipError_t launch_render_small(const RenderArgs &A, const float *host_tri16, hipStream_t stream)
+hipError_t launch_render_small(const RenderArgs &A, const SmallHost &hs, hipStream_t stream)
 {
-  if (A.sc.ns + A.sc.nt > 64 || !A.utab || !A.vtab || (A.sc.nt > 0 && !host_tri16)) return hipErrorInvalidValue;
+  if (A.sc.ns + A.sc.nt > 64 || !A.utab || !A.vtab || hs.ns != A.sc.ns || hs.nt != A.sc.nt) return hipErrorInvalidValue;
   switch (small_pixels_per_lane()) {
-  case 1: return launch_small<1>(A, host_tri16, stream);
-  case 4: return launch_small<4>(A, host_tri16, stream);
-  default: return launch_small<2>(A, host_tri16, stream);
+  case 1: return launch_small<1>(A, hs, stream);
+  case 4: return launch_small<4>(A, hs, stream);
+  default: return launch_small<2>(A, hs, stream);
   }
 }
 
