@@ -105,3 +105,38 @@ def test_cpp_host_layer_compiles_standalone(tmp_path):
     src.write_text("".join(f'#include "{h}"\n' for h in hdrs) + "int main() { return 0; }\n")
     subprocess.check_call(["g++", "-std=c++17", "-fsyntax-only", "-Wall", "-I", host, "-I", os.path.join(ROOT, "include"),
                            str(src)])
+
+
+def test_triangle_bound_contains_every_accepted_point():
+    """mrt_triangle_bound (host only): the ball the culling kernels use must contain every point the exact
+    hit test (oracle) accepts.  Rays are shot at points inside and just outside the triangle; whenever the
+    oracle reports a hit, the hit point lies inside the ball.  A triangle whose plane passes through the
+    world origin has degenerate edge planes (dir x point_inside with a position vector): unbounded, +inf."""
+    rng = np.random.default_rng(11)
+    n_finite = 0
+    for it in range(60):
+        a = rng.uniform(-20, 20, 3)
+        size = 10.0 ** rng.uniform(-1.5, 1.3)
+        tri = np.stack([a, a + rng.normal(size=3) * size, a + rng.normal(size=3) * size]).astype(np.float32)
+        t16 = capi.triangle_precompute(tri)[:, 0]
+        ball = capi.triangle_bound(t16)
+        if not np.isfinite(ball[3]):
+            continue
+        n_finite += 1
+        w = rng.uniform(-0.3, 1.3, (200, 3)); w /= w.sum(1, keepdims=True)
+        targets = (w[:, :, None] * tri.astype(np.float64)[None]).sum(1)
+        origin = a + rng.normal(size=3) * 30.0
+        for tgt in targets:
+            d = (tgt - origin).astype(np.float32)
+            ok, _, point, _ = O.triangle16_hit(t16, origin.astype(np.float32), d, 0.01, float("inf"))
+            if ok:
+                dist = np.linalg.norm(point.astype(np.float64) - ball[:3].astype(np.float64))
+                assert dist <= ball[3], (it, dist, ball)
+    assert n_finite >= 30
+    # vertices are inside their own triangle's ball
+    tri = np.array([[1, 2, -5], [4, 2, -6], [2, 5, -7]], np.float32)
+    ball = capi.triangle_bound(capi.triangle_precompute(tri)[:, 0])
+    assert np.isfinite(ball[3]) and all(np.linalg.norm(v - ball[:3]) <= ball[3] for v in tri)
+    # plane through the world origin: never culled
+    tri0 = np.array([[0, 0, 0], [4, 1, -6], [2, 5, -7]], np.float32)
+    assert capi.triangle_bound(capi.triangle_precompute(tri0)[:, 0])[3] == np.inf
