@@ -100,7 +100,9 @@ typedef struct mrt_partition {
 typedef struct mrt_render_params {
   int32_t width, height;  /* full frame */
   int32_t spp;            /* 1: one sample at (col/W,row/H); 121: rt::MultisampleMesh (pipeline/multisample_mesh.cuh) */
-  int32_t max_depth;      /* config::MAX_RECURSION_DEPTH (src/main.cu:26); 0 = primary + shadow */
+  int32_t max_depth;      /* config::MAX_RECURSION_DEPTH (src/main.cu:26); 0 = primary + shadow; 1..8 = mirror
+                             chains (src/main.cu:79-98), accepted only when every material is metallic:
+                             a diffuse bounce draws from cuRAND (core/material.cuh:52-61), not implemented */
   mrt_partition part;
 } mrt_render_params;
 

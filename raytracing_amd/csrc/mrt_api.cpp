@@ -29,6 +29,7 @@ struct mrt_ctx {
   size_t scene_bytes = 0;
   mrt::DevScene sc{};
   bool have_scene = false;
+  bool any_diffuse = false; // mirror chains (max_depth > 0) need an all-metallic scene
 
   // output staging for the blocking host-buffer entry point
   void *out_mem = nullptr;
@@ -102,6 +103,7 @@ static hipError_t ensure_uv_tables(mrt_ctx *ctx, int W, int H, hipStream_t st)
 
 static hipError_t launch_by_mode(mrt_ctx *ctx, mrt::RenderArgs &A, hipStream_t st)
 {
+  if (A.max_depth > 0) return mrt::launch_render_bounce(A, st); // mirror chains: one kernel, every ray x every primitive
   int mode = ctx->cull;
   const bool small = (long)A.sc.ns + A.sc.nt <= 64;
   // measured: the small-scene kernel wins where it applies; with the primitive-side hierarchy the
@@ -553,6 +555,8 @@ int mrt_scene_upload(mrt_ctx *ctx, const mrt_scene_desc *s)
   d.mat_kind = b + o_mk; d.mat_rgb = (const float *)(b + o_mrgb); d.nobj = (int32_t)no;
   d.light_kind = b + o_lk; d.light_vec = (const float *)(b + o_lv); d.light_rgb = (const float *)(b + o_lc);
   d.nl = (int32_t)nl;
+  ctx->any_diffuse = false;
+  for (size_t i = 0; i < no; ++i) ctx->any_diffuse |= (s->mat_kind[i] == MRT_MAT_DIFFUSE);
   ctx->have_scene = true;
   return MRT_OK;
 }
@@ -587,7 +591,9 @@ static int fill_args(mrt_ctx *ctx, const mrt_camera *cam, const mrt_render_param
   if (p->width <= 0 || p->height <= 0) return fail(ctx, MRT_ERR_INVALID, "non-positive frame size");
   if (p->width > 65536 || p->height > 65536) return fail(ctx, MRT_ERR_TOO_LARGE, "frame larger than 65536 in a dimension");
   if (p->spp != 1 && p->spp != 121) return fail(ctx, MRT_ERR_INVALID, "spp must be 1 or 121");
-  if (p->max_depth != 0) return fail(ctx, MRT_ERR_INVALID, "only max_depth 0 (primary + shadow) is implemented");
+  if (p->max_depth < 0 || p->max_depth > 8) return fail(ctx, MRT_ERR_INVALID, "max_depth must be 0..8");
+  if (p->max_depth > 0 && ctx->any_diffuse)
+    return fail(ctx, MRT_ERR_INVALID, "max_depth > 0 needs an all-metallic scene (diffuse bounces draw random numbers: not implemented)");
   if (!partition_ok(p->part)) return fail(ctx, MRT_ERR_INVALID, "bad strip partition");
   std::memset(&A, 0, sizeof A);
   A.sc = ctx->sc;
@@ -599,6 +605,7 @@ static int fill_args(mrt_ctx *ctx, const mrt_camera *cam, const mrt_render_param
   A.rank = p->part.rank; A.nranks = p->part.num_ranks; A.strip_rows = p->part.strip_rows;
   A.local_rows = local_rows_of(p->height, p->part);
   A.spp = p->spp;
+  A.max_depth = p->max_depth;
   return MRT_OK;
 }
 

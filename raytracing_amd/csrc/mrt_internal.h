@@ -59,6 +59,7 @@ struct RenderArgs {
   int32_t rank, nranks, strip_rows; // strip partition
   int32_t local_rows;
   int32_t spp;                      // 1 or 121
+  int32_t max_depth;                // 0: primary + shadow; 1..8: mirror chains (mrt_bounce.hip)
   float *rgb;                       // [local_rows*W*3]
   int32_t *id;                      // [local_rows*W] or null
   float *t;                         // [local_rows*W] or null
@@ -87,6 +88,9 @@ struct SmallHost {
 };
 hipError_t launch_render_small(const RenderArgs &args, const SmallHost &host, hipStream_t stream);
 hipError_t launch_uv_table(float *utab, int nu, int W, float *vtab, int nv, int H, hipStream_t stream);
+
+// mirror chains, max_depth 1..8, all-metallic scenes (mrt_bounce.hip)
+hipError_t launch_render_bounce(const RenderArgs &args, hipStream_t stream);
 
 // launchers (mrt_kernels.hip)
 hipError_t launch_render(const RenderArgs &args, hipStream_t stream);

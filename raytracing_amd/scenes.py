@@ -149,6 +149,24 @@ def triangle_terrain(nx=1000, nz=500):
                      _camera(40.0))
 
 
+def mirror_hall(n_spheres=24, seed=1984):
+    """All-metallic scene for the mirror-chain path (max_depth > 0): a floor, a back wall and two
+    side walls (two triangles each) around a cloud of spheres, one directional and one point light."""
+    sp = random_spheres(n_spheres, seed, box=((-6.0, 6.0), (-2.0, 3.0), (-24.0, -12.0)), radii=(0.4, 1.4))
+    def quad(p, e1, e2):
+        p, e1, e2 = (np.asarray(x, np.float32) for x in (p, e1, e2))
+        return [[p, p + e1, p + e1 + e2], [p, p + e1 + e2, p + e2]]
+    tv = np.asarray(quad((-9, -3.5, -8), (18, 0, 0), (0, 0, -20)) + quad((-9, -3.5, -28), (18, 0, 0), (0, 9, 0)) +
+                    quad((-9, -3.5, -8), (0, 0, -20), (0, 9, 0)) + quad((9, -3.5, -8), (0, 9, 0), (0, 0, -20)), np.float32)
+    n = n_spheres + len(tv)
+    u = _splitmix64(seed + 7, 3 * n).reshape(n, 3)
+    rgb = (np.float32(0.35) + np.float32(0.6) * u).astype(np.float32)
+    kind = np.full(n, MAT_METALLIC, np.uint8)
+    lights = _default_lights() + [(LIGHT_POINT, (0.0, 4.5, -14.0), (2.0, 2.0, 2.0))]
+    return SceneSpec(f"mirror_hall_{n_spheres}", sp, np.arange(n_spheres), tv, n_spheres + np.arange(len(tv)), kind, rgb,
+                     lights, _camera(40.0))
+
+
 def light_stress(n_spheres=256, n_tris=256, grid=8, seed=1984):
     """C5: spheres and triangles interleaved in object order + grid*grid point lights at y = 12."""
     sp = random_spheres(n_spheres, seed, box=((-12.0, 12.0), (-3.0, 3.0), (-45.0, -12.0)), radii=(0.3, 1.0))

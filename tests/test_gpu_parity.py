@@ -455,6 +455,79 @@ def test_random_small_scenes_vs_oracle(gpu_ctx, seed):
     assert_stats_parity(g["stats"], r["stats"])
 
 
+
+# ------------------------------------------------------------------ mirror chains (max_depth > 0)
+
+def _only_once(kernel_mode):
+    if kernel_mode != "brute":
+        pytest.skip("max_depth > 0 always runs render_bounce_kernel: one pass is enough")
+
+
+@pytest.mark.parametrize("depth", [1, 2, 8])
+def test_mirror_chains_vs_oracle(gpu_ctx, kernel_mode, depth):
+    """config::MAX_RECURSION_DEPTH > 0 on an all-metallic scene (src/main.cu:79-98, material.cuh:126-158):
+    the iterative chain + fold must reproduce the oracle's recursion bit for bit."""
+    _only_once(kernel_mode)
+    spec = scenes.mirror_hall()
+    gpu_ctx.upload(spec.flatten())
+    W, H = 256, 144
+    cam = spec.cam12(W / H)
+    g = gpu_ctx.render(cam, W, H, max_depth=depth)
+    r = O.Scene.from_spec(spec).render(cam, W, H, max_depth=depth, nthreads=8)
+    assert_frame_parity(g, r, f"mirror hall depth {depth}")
+    assert_stats_parity(g["stats"], r["stats"])
+    g0 = gpu_ctx.render(cam, W, H, max_depth=0)
+    assert np.array_equal(g0["id"], g["id"]) and np.array_equal(g0["t"], g["t"])   # ID / t describe the primary hit
+    assert (g0["rgb"] != g["rgb"]).any() and g["stats"]["shadow_rays"] > g0["stats"]["shadow_rays"]
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_mirror_chains_random_scenes(gpu_ctx, kernel_mode, seed):
+    _only_once(kernel_mode)
+    spec = _random_scene(seed) if seed % 2 else _random_small_scene(seed)
+    spec.mat_kind[:] = capi.MAT_METALLIC
+    spec.mat_rgb[:] = (0.2 + 0.75 * np.random.default_rng(seed).random(spec.mat_rgb.shape)).astype(np.float32)
+    gpu_ctx.upload(spec.flatten())
+    W, H = 136, 104
+    cam = spec.cam12(W / H)
+    g = gpu_ctx.render(cam, W, H, max_depth=8)
+    r = O.Scene.from_spec(spec).render(cam, W, H, max_depth=8, nthreads=8)
+    assert_frame_parity(g, r, spec.name)
+    assert_stats_parity(g["stats"], r["stats"])
+
+
+def test_mirror_chains_multisample_and_strips(gpu_ctx, kernel_mode):
+    _only_once(kernel_mode)
+    spec = scenes.mirror_hall(8)
+    gpu_ctx.upload(spec.flatten())
+    W, H = 96, 56
+    cam = spec.cam12(W / H)
+    ora = O.Scene.from_spec(spec)
+    g = gpu_ctx.render(cam, W, H, spp=121, max_depth=3)
+    r = ora.render(cam, W, H, spp=121, max_depth=3, nthreads=8)
+    assert_frame_parity(g, r, "mirror hall 121 spp")
+    full = gpu_ctx.render(cam, W, H, max_depth=4)
+    for rank in range(3):   # strips of a 3-rank partition reassemble the 1-GPU frame
+        part = gpu_ctx.render(cam, W, H, max_depth=4, rank=rank, num_ranks=3, strip_rows=8)
+        rows = capi.local_row_index(H, rank, 3, 8)
+        for k in ("rgb", "id", "t"):
+            assert np.array_equal(part[k], full[k][rows]), (rank, k)
+
+
+def test_mirror_chain_error_paths(gpu_ctx, kernel_mode):
+    _only_once(kernel_mode)
+    flat, _ = scenes.default_scene()          # has diffuse objects
+    gpu_ctx.upload(flat)
+    cam = capi.default_viewport(2.0)
+    with pytest.raises(capi.MrtError, match="all-metallic"):
+        gpu_ctx.render(cam, 64, 32, max_depth=1)
+    gpu_ctx.upload(scenes.mirror_hall(4).flatten())
+    with pytest.raises(capi.MrtError, match="max_depth"):
+        gpu_ctx.render(cam, 64, 32, max_depth=9)
+    with pytest.raises(capi.MrtError, match="max_depth"):
+        gpu_ctx.render(cam, 64, 32, max_depth=-1)
+
+
 # ------------------------------------------------------------------ strips (multi-GPU partition on one GPU)
 
 @pytest.mark.parametrize("nranks,strip", [(2, 8), (3, 8), (8, 8), (4, 16)])
