@@ -170,19 +170,20 @@ def main():
     for _ in range(warmup):
         fr.step()
     sync()
-    # HIP events on the stream the kernel is launched on (torch's current stream), around the render
-    # kernel only (the gather/assembly follow the second event).  Every 8th step is sampled so that
-    # recording does not open gaps between the back-to-back launches of a frame that lasts ~30 us.
-    stride = 8 if steps >= 64 else 1
+    # HIP events on the stream the kernel is launched on (torch's current stream).  At N=1 with many steps the
+    # events bracket groups of 8 back-to-back launches (a frame lasts ~20 us; an event pair around a single
+    # launch adds its own microsecond or two) and the group time is divided by 8; otherwise they bracket the
+    # render kernel of every step (the gather/assembly follow the second event).
+    group = 8 if (world == 1 and steps >= 64) else 1
     ev = {k: (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-          for k in range(0, steps, stride)}
+          for k in range(0, steps - group + 1, group)}
     t0 = time.perf_counter()
     for k in range(steps):
-        e = ev.get(k)
-        if e:
+        e = ev.get(k - k % group)
+        if e and k % group == 0:
             e[0].record()
         fr.render_local()
-        if e:
+        if e and k % group == group - 1:
             e[1].record()
         if world > 1:
             multigpu.gather_strips(fr.rgb, world, rank, dst=0, out=fr.gathered)
@@ -195,7 +196,7 @@ def main():
     if world > 1:
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
     elapsed = float(el.item())
-    kern_ms = sum(a.elapsed_time(b) for a, b in ev.values()) / len(ev)
+    kern_ms = sum(a.elapsed_time(b) for a, b in ev.values()) / (len(ev) * group)
 
     if rank == 0:
         ms_per_step = elapsed / steps * 1e3
