@@ -131,10 +131,16 @@ def main():
         args.gpus = world
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: there is no CPU fallback of the product path")
+    if os.environ.get("MRT_BENCH_BACKEND", "nccl") != "nccl":
+        local_rank = local_rank % torch.cuda.device_count()  # rehearsal: ranks share the GPUs there are
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+        backend = os.environ.get("MRT_BENCH_BACKEND", "nccl")  # "gloo": rehearsal on a box with fewer GPUs than ranks
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+        else:
+            dist.init_process_group(backend)
 
     def progress(msg):  # stderr only: stdout carries the one JSON line
         if rank == 0:

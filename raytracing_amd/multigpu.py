@@ -29,6 +29,16 @@ def gather_strips(local, num_ranks, rank, dst=0, group=None, out=None):
 
     if num_ranks == 1:
         return local.view(1, -1)
+    if local.is_cuda and dist.get_backend(group) == "gloo":
+        # rehearsal of the N > 1 path on a box without N GPUs (bench.py MRT_BENCH_BACKEND=gloo): stage through
+        # the host; the product path is the RCCL gather below
+        host = gather_strips(local.cpu(), num_ranks, rank, dst, group)
+        if rank != dst:
+            return None
+        if out is None:
+            out = torch.empty((num_ranks, local.numel()), dtype=local.dtype, device=local.device)
+        out.copy_(host)
+        return out
     if rank == dst:
         if out is None:
             out = torch.empty((num_ranks, local.numel()), dtype=local.dtype, device=local.device)
