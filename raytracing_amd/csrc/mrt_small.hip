@@ -76,9 +76,13 @@ __device__ __forceinline__ float wave_max_dpp(float x)
 constexpr int SH_STRIDE = 3 * 7 + 2; // floats per (light, triangle): 3 edges x (gx, gy, gz, off, gn, a, b) + sign guard
 
 template <int P> struct VecOf;
-template <> struct VecOf<1> { using f = float; using i = int; };
-template <> struct VecOf<2> { using f = float2; using i = int2; };
-template <> struct VecOf<4> { using f = float4; using i = int4; };
+typedef float nfloat2 __attribute__((ext_vector_type(2)));
+typedef float nfloat4 __attribute__((ext_vector_type(4)));
+typedef int nint2 __attribute__((ext_vector_type(2)));
+typedef int nint4 __attribute__((ext_vector_type(4)));
+template <> struct VecOf<1> { using f = float; using i = int; using nf = float; using ni = int; };
+template <> struct VecOf<2> { using f = float2; using i = int2; using nf = nfloat2; using ni = nint2; };
+template <> struct VecOf<4> { using f = float4; using i = int4; using nf = nfloat4; using ni = nint4; };
 
 __device__ __forceinline__ float abs1(float x, float y, float z) { return fabsf(x) + fabsf(y) + fabsf(z); }
 
@@ -510,10 +514,13 @@ __device__ __forceinline__ void render_small_body(const SmallArgs &S)
 #pragma unroll
     for (int p = 0; p < P; ++p) { o[3 * p] = accr[p]; o[3 * p + 1] = accg[p]; o[3 * p + 2] = accb[p]; }
     VF *dst = reinterpret_cast<VF *>(A.rgb + 3 * pix0);
+    // the frame is written once and not read again by this kernel: streaming (non-temporal) stores
+    using NF = typename VecOf<P>::nf;
+    using NI = typename VecOf<P>::ni;
 #pragma unroll
-    for (int k = 0; k < 3; ++k) dst[k] = *reinterpret_cast<const VF *>(&o[P * k]);
-    if (A.id) *reinterpret_cast<VI *>(A.id + pix0) = *reinterpret_cast<const VI *>(&out_id[0]);
-    if (A.t) *reinterpret_cast<VF *>(A.t + pix0) = *reinterpret_cast<const VF *>(&out_t[0]);
+    for (int k = 0; k < 3; ++k) __builtin_nontemporal_store(*reinterpret_cast<const NF *>(&o[P * k]), reinterpret_cast<NF *>(dst) + k);
+    if (A.id) __builtin_nontemporal_store(*reinterpret_cast<const NI *>(&out_id[0]), reinterpret_cast<NI *>(A.id + pix0));
+    if (A.t) __builtin_nontemporal_store(*reinterpret_cast<const NF *>(&out_t[0]), reinterpret_cast<NF *>(A.t + pix0));
   } else {
 #pragma unroll
     for (int p = 0; p < P; ++p)
