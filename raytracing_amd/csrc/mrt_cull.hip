@@ -285,6 +285,7 @@ __global__ __launch_bounds__(256) void render_cull_kernel(RenderArgs A)
           B.Dx = lvx - B.mx; B.Dy = lvy - B.my; B.Dz = lvz - B.mz;
         }
         B.DD = dot3(B.Dx, B.Dy, B.Dz, B.Dx, B.Dy, B.Dz);
+        bundle_make_slab(B, cax, cay, caz, hpx - B.mx, hpy - B.my, hpz - B.mz, have_hit);
         const float sa = dot3(sdx, sdy, sdz, sdx, sdy, sdz);
         // the light must not shine through the surface, core/light.cuh:148
         const bool need = have_hit && !(dot3(sdx, sdy, sdz, hnx, hny, hnz) < 0);

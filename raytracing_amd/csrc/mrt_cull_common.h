@@ -100,13 +100,42 @@ struct Bundle {
   float mx, my, mz, rho;   // hit points of the tile lie within rho of m
   float Dx, Dy, Dz, DD;    // directional: ray direction and D.D;  point: e = pos - m and e.e
   bool point;
+  // Optional slab |n.(x - m)| <= sw that holds every shadow ray of the tile: n is the unit normal of the plane
+  // through m spanned by the tile's view axis and the light direction (resp. the direction to a point light).
+  // The tile's hit points lie along the view axis, so they -- and with them their shadow rays, which move
+  // inside that plane -- stay within a small sw of it even when they are spread over a large depth range
+  // (where the ball (m, rho) is huge).  sw = +inf: no slab.
+  float snx = 0.0f, sny = 0.0f, snz = 0.0f, sw = MRT_INF;
 };
+
+// Build the slab of B for the current light (B.D set): a = unit view axis of the tile, (ex, ey, ez) = this lane's
+// hit point minus m, have = this lane has a hit point.  Wave-uniform result.
+__device__ __forceinline__ void bundle_make_slab(Bundle &B, float ax, float ay, float az, float ex, float ey, float ez,
+                                                 bool have)
+{
+  float nx = ay * B.Dz - az * B.Dy, ny = az * B.Dx - ax * B.Dz, nz = ax * B.Dy - ay * B.Dx;
+  const float nn = dot3(nx, ny, nz, nx, ny, nz);
+  B.snx = 0.0f; B.sny = 0.0f; B.snz = 0.0f; B.sw = MRT_INF;
+  // the angle between axis and direction must be at least ~3 degrees: below that the normal is ill-conditioned
+  // (its rounding error is 6e-8 / sin) and the slab is not used
+  if (nn > 2.5e-3f * B.DD) {
+    const float inv = fast_rsq(nn);
+    nx *= inv; ny *= inv; nz *= inv;
+    const float w = wave_max(have ? fabsf(dot3(nx, ny, nz, ex, ey, ez)) : 0.0f);
+    B.snx = nx; B.sny = ny; B.snz = nz;
+    // a point light's own offset from the plane is pure rounding: |n.(L - m)| <= 1.2e-6 |L - m|
+    B.sw = w * CULL_REL + CULL_ABS + (B.point ? 1e-5f * norm1(B.Dx, B.Dy, B.Dz) : 0.0f);
+  }
+}
 
 // Does the ball (centre c, squared radius rr for spheres / radius rb for triangle bounds) possibly touch
 // one of the tile's shadow rays?
 __device__ __forceinline__ bool bundle_may_touch(const Bundle &B, float cx, float cy, float cz, float reff)
 {
   const float wx = cx - B.mx, wy = cy - B.my, wz = cz - B.mz;
+  // slab: a shadow ray reaches at most |c - m| + reff along its direction before it can touch the ball, and drifts
+  // off the (rounded) plane by at most 1.2e-6 of that
+  if (fabsf(dot3(B.snx, B.sny, B.snz, wx, wy, wz)) > B.sw + reff * CULL_REL + 1e-5f * (norm1(wx, wy, wz) + reff)) return false;
   const float reach = (reff + B.rho) * CULL_REL + CULL_ABS;
   return B.point ? ball_may_touch_segment(wx, wy, wz, reach, B.Dx, B.Dy, B.Dz, B.DD)
                  : ball_may_touch_sweep(wx, wy, wz, reach, B.Dx, B.Dy, B.Dz, B.DD);
