@@ -129,7 +129,7 @@ static hipError_t launch_by_mode(mrt_ctx *ctx, mrt::RenderArgs &A, hipStream_t s
 }
 
 // ---- primitive-side hierarchy (camera independent, built once per upload) ----
-// Primitives of each type are stored in Morton order of their bound centres, and every run of 64 consecutive
+// Primitives of each type are stored in kd order (default; Morton order for ablation) of their bound centres, and every run of 64 consecutive
 // primitives ("cluster") gets a bounding ball.  The culling kernels test clusters first.  Reordering is
 // invisible in the results: hits are reported by object number, and the closest-hit rule
 // (t, object number) lexicographic minimum does not depend on the visiting order.
@@ -173,6 +173,55 @@ template <class BoundFn> static void morton_order(size_t n, BoundFn bound, std::
     key[i] = spread10(q[0]) | (spread10(q[1]) << 1) | (spread10(q[2]) << 2);
   }
   std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return key[a] < key[b]; });
+}
+
+// Alternative order: recursive median split along the longest axis of the centres, with every split position a
+// multiple of 64 (of 4096 while the range is larger than that), so that each run of 64 consecutive primitives
+// is a leaf of a kd-tree and each run of 64 clusters a subtree: compact clusters, where a run of 64 along a
+// Morton curve can straddle a long jump of the curve.  Unbounded primitives go last, as in morton_order.
+static void kd_split(uint32_t *idx, size_t lo, size_t hi, const float *c)
+{
+  const size_t n = hi - lo;
+  if (n <= 64) return;
+  const size_t unit = n > 4096 ? 4096 : 64;
+  size_t mid = lo + ((n / 2 + unit / 2) / unit) * unit;
+  if (mid <= lo) mid = lo + unit;
+  if (mid >= hi) mid = lo + ((n - 1) / unit) * unit;
+  if (mid <= lo || mid >= hi) return;
+  float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+  for (size_t i = lo; i < hi; ++i)
+    for (int a = 0; a < 3; ++a) { const float v = c[4 * idx[i] + a]; mn[a] = std::fmin(mn[a], v); mx[a] = std::fmax(mx[a], v); }
+  int axis = 0;
+  if (mx[1] - mn[1] > mx[axis] - mn[axis]) axis = 1;
+  if (mx[2] - mn[2] > mx[axis] - mn[axis]) axis = 2;
+  std::nth_element(idx + lo, idx + mid, idx + hi,
+                   [&](uint32_t a, uint32_t b) { return c[4 * a + axis] < c[4 * b + axis]; });
+  kd_split(idx, lo, mid, c);
+  kd_split(idx, mid, hi, c);
+}
+
+template <class BoundFn> static void kd_order(size_t n, BoundFn bound, std::vector<uint32_t> &order)
+{
+  order.clear();
+  order.reserve(n);
+  std::vector<float> c(4 * n);
+  std::vector<uint32_t> unbounded;
+  for (size_t i = 0; i < n; ++i) {
+    bound(i, &c[4 * i]);
+    const float *b = &c[4 * i];
+    if (std::isfinite(b[3]) && std::isfinite(b[0]) && std::isfinite(b[1]) && std::isfinite(b[2])) order.push_back((uint32_t)i);
+    else unbounded.push_back((uint32_t)i);
+  }
+  if (n > 64) kd_split(order.data(), 0, order.size(), c.data());
+  order.insert(order.end(), unbounded.begin(), unbounded.end());
+}
+
+// MRT_ORDER=morton selects the Morton order (ablation); default: kd order
+template <class BoundFn> static void primitive_order(size_t n, BoundFn bound, std::vector<uint32_t> &order)
+{
+  static const bool morton = [] { const char *e = getenv("MRT_ORDER"); return e && std::strcmp(e, "morton") == 0; }();
+  if (morton) morton_order(n, bound, order);
+  else kd_order(n, bound, order);
 }
 
 // bounding ball of each run of 64 balls (streams x,y,z,r of n floats) -> 4 streams of ceil(n/64) floats
@@ -465,9 +514,9 @@ int mrt_scene_upload(mrt_ctx *ctx, const mrt_scene_desc *s)
   try { img.assign(total, 0); } catch (...) { return fail(ctx, MRT_ERR_INVALID, "out of host memory"); }
   auto put = [&](size_t o, const void *src, size_t bytes) { if (bytes) std::memcpy(img.data() + o, src, bytes); };
   {
-    // spheres, in Morton order
+    // spheres, in kd order
     std::vector<uint32_t> order;
-    morton_order(ns, [&](size_t i, float *b) { b[0] = s->sphere_cx[i]; b[1] = s->sphere_cy[i]; b[2] = s->sphere_cz[i];
+    primitive_order(ns, [&](size_t i, float *b) { b[0] = s->sphere_cx[i]; b[1] = s->sphere_cy[i]; b[2] = s->sphere_cz[i];
                                                b[3] = s->sphere_r[i]; }, order);
     float *cx = (float *)(img.data() + o_cx), *cy = (float *)(img.data() + o_cy), *cz = (float *)(img.data() + o_cz);
     float *r = (float *)(img.data() + o_r);
@@ -493,7 +542,7 @@ int mrt_scene_upload(mrt_ctx *ctx, const mrt_scene_desc *s)
     cluster_bounds(cs, cs + ncs, cs + 2 * ncs, cs + 3 * ncs, ncs, (float *)(img.data() + o_scs));
   }
   {
-    // triangles: bounds of the accepted regions first, then Morton order of those
+    // triangles: bounds of the accepted regions first, then kd order of those
     std::vector<float> tb(4 * nt);
     for (size_t i = 0; i < nt; ++i) {
       float q[16];
@@ -501,7 +550,7 @@ int mrt_scene_upload(mrt_ctx *ctx, const mrt_scene_desc *s)
       tri_bound(q, &tb[4 * i]);
     }
     std::vector<uint32_t> order;
-    morton_order(nt, [&](size_t i, float *b) { std::memcpy(b, &tb[4 * i], 16); }, order);
+    primitive_order(nt, [&](size_t i, float *b) { std::memcpy(b, &tb[4 * i], 16); }, order);
     float *tri = (float *)(img.data() + o_tri), *bnd = (float *)(img.data() + o_tb), *rec = (float *)(img.data() + o_trec);
     int32_t *to = (int32_t *)(img.data() + o_to);
     for (size_t i = 0; i < nt; ++i) {

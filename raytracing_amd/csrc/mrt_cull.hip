@@ -4,7 +4,7 @@
 // results of that loop depend only on the primitives a ray can actually hit, so this kernel first asks,
 // once per 8x8 pixel tile (one wave64), which primitives can be hit by ANY ray of the tile:
 //
-//   * primitives are stored in Morton order with bounding balls for every 64 primitives (cluster) and every
+//   * primitives are stored in kd order (mrt_api.cpp) with bounding balls for every 64 primitives (cluster) and every
 //     64 clusters (super-cluster), built at upload (mrt_api.cpp).  At each level the 64 lanes each take a
 //     DIFFERENT ball (coalesced SoA loads: 64 balls per instruction) and test it against a bound of the
 //     tile's ray bundle
@@ -32,7 +32,7 @@
 namespace mrt {
 
 // ---- primitive-side hierarchy walk ---------------------------------------------------------------------
-// Primitives are stored in Morton order; runs of 64 primitives have a bounding ball ("cluster"), runs of 64
+// Primitives are stored in kd order; runs of 64 primitives have a bounding ball ("cluster"), runs of 64
 // clusters another one ("super-cluster").  A wave walks the hierarchy with lane-parallel tests at every
 // level: 64 super-clusters per step, then the 64 clusters of each surviving super-cluster, then
 // body(first primitive of the cluster) for each surviving cluster.  A level with a single entry is not

@@ -6,7 +6,7 @@
 
 namespace mrt {
 
-// Scene as it lives in HBM: pure SoA streams, one allocation.  Primitives of a type are stored in Morton
+// Scene as it lives in HBM: pure SoA streams, one allocation.  Primitives of a type are stored in kd
 // order of their bound centres (mrt_api.cpp); *_obj carries the object number every result is reported in.
 struct DevScene {
   // spheres: 4 streams of ns floats (core/sphere.cuh:116-117) + object numbers
@@ -26,7 +26,7 @@ struct DevScene {
   // mrt_api.cpp shadow_functions, used by mrt_small.hip)
   const float *tri_shfn;
   int32_t nls;
-  // bounding balls of runs of 64 consecutive primitives (primitives are stored in Morton order):
+  // bounding balls of runs of 64 consecutive primitives (primitives are stored in kd order):
   // 4 streams (x, y, z, r) of ncs / nct floats each
   const float *sph_clu, *tri_clu;
   int32_t ncs, nct;
