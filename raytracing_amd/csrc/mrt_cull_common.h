@@ -21,18 +21,33 @@ namespace mrt {
 // of those lengths as slack.  Only the exact tests behind the bounds need exact arithmetic.
 #define CULL_LEN_SLACK 4e-6f
 
+__device__ __forceinline__ float bcast(float x, int lane)
+{
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), lane));
+}
+// Reductions over the wave with DPP row operations (no LDS traffic); the result is wave-uniform.
+#define MRT_DPP_STEP(OP, ctrl, row_mask)                                                                      \
+  x = OP(x, __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(x), __float_as_int(x), ctrl, row_mask, \
+                                                       0xf, false)))
+#define MRT_DPP_REDUCE(OP)                                                                          \
+  MRT_DPP_STEP(OP, 0xB1, 0xf);  /* quad_perm [1,0,3,2] */                                            \
+  MRT_DPP_STEP(OP, 0x4E, 0xf);  /* quad_perm [2,3,0,1] */                                            \
+  MRT_DPP_STEP(OP, 0x141, 0xf); /* row_half_mirror */                                                \
+  MRT_DPP_STEP(OP, 0x140, 0xf); /* row_mirror: every lane of a row of 16 holds the row's result */   \
+  MRT_DPP_STEP(OP, 0x142, 0xa); /* row_bcast:15 into rows 1 and 3 */                                 \
+  MRT_DPP_STEP(OP, 0x143, 0xc); /* row_bcast:31 into rows 2 and 3: lane 63 holds the wave's result */
 __device__ __forceinline__ float wave_max(float x)
 {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) x = fmaxf(x, __shfl_xor(x, off, 64));
-  return x;
+  MRT_DPP_REDUCE(fmaxf)
+  return bcast(x, 63);
 }
 __device__ __forceinline__ float wave_min(float x)
 {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) x = fminf(x, __shfl_xor(x, off, 64));
-  return x;
+  MRT_DPP_REDUCE(fminf)
+  return bcast(x, 63);
 }
+#undef MRT_DPP_REDUCE
+#undef MRT_DPP_STEP
 // single-instruction approximations (1 ulp), for bound tests only
 __device__ __forceinline__ float fast_sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
 __device__ __forceinline__ float fast_rsq(float x) { return __builtin_amdgcn_rsqf(x); }
@@ -41,10 +56,6 @@ __device__ __forceinline__ void fast_normalize(float &x, float &y, float &z)
 {
   const float s = fast_rsq(dot3(x, y, z, x, y, z));
   x *= s; y *= s; z *= s;
-}
-__device__ __forceinline__ float bcast(float x, int lane)
-{
-  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), lane));
 }
 
 // effective radius of a sphere of squared radius rr seen from distance <= Lmax

@@ -57,22 +57,6 @@ hipError_t launch_uv_table(float *utab, int nu, int W, float *vtab, int nv, int 
   return hipGetLastError();
 }
 
-// max over the wave with DPP row operations (no LDS traffic); the result is wave-uniform
-__device__ __forceinline__ float wave_max_dpp(float x)
-{
-#define MRT_DPP_MAX(ctrl, row_mask)                                                                              \
-  x = fmaxf(x, __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(x), __float_as_int(x), ctrl, row_mask, \
-                                                          0xf, false)))
-  MRT_DPP_MAX(0xB1, 0xf);  // quad_perm [1,0,3,2]
-  MRT_DPP_MAX(0x4E, 0xf);  // quad_perm [2,3,0,1]
-  MRT_DPP_MAX(0x141, 0xf); // row_half_mirror
-  MRT_DPP_MAX(0x140, 0xf); // row_mirror: every lane of a row of 16 holds the row's maximum
-  MRT_DPP_MAX(0x142, 0xa); // row_bcast:15 into rows 1 and 3
-  MRT_DPP_MAX(0x143, 0xc); // row_bcast:31 into rows 2 and 3: lane 63 holds the wave's maximum
-#undef MRT_DPP_MAX
-  return bcast(x, 63);
-}
-
 constexpr int SH_STRIDE = 3 * 7 + 2; // floats per (light, triangle): 3 edges x (gx, gy, gz, off, gn, a, b) + sign guard
 
 template <int P> struct VecOf;
@@ -330,7 +314,7 @@ __device__ __forceinline__ void render_small_body(const SmallArgs &S)
           const float ex = hpx[p] - mx, ey = hpy[p] - my, ez = hpz[p] - mz;
           e2max = fmaxf(e2max, have_hit[p] ? dot3(ex, ey, ez, ex, ey, ez) : 0.0f);
         }
-        B.rho = fast_sqrt(wave_max_dpp(e2max)) * CULL_REL + CULL_ABS;
+        B.rho = fast_sqrt(wave_max(e2max)) * CULL_REL + CULL_ABS;
       }
       // distance bound from the bundle centre for the sphere this lane owns (>= |hit point - centre|)
       float Lm2 = 0.0f;
