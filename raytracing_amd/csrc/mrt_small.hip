@@ -641,20 +641,23 @@ static hipError_t launch_small(const RenderArgs &in, const SmallHost &hs, hipStr
   return hipGetLastError();
 }
 
-int small_pixels_per_lane()
+// Pixels per lane.  Measured on the default scene: 2 for one sample per pixel (21.5 us against 23.3
+// with 1 and 27 with 4 at 1080p), 1 for the 121-sample mode (2.20 ms against 2.34 at the reference's 2048x1024:
+// the multi-sample instantiation needs 124 registers at 2 pixels per lane).  MRT_SMALL_P = 1 | 2 | 4 overrides.
+static int small_pixels_per_lane(int spp)
 {
-  static const int v = [] {
+  static const int forced = [] {
     const char *e = getenv("MRT_SMALL_P");
-    const int x = e ? atoi(e) : 2; // measured on C2: 2 pixels per lane is the fastest
-    return (x == 1 || x == 2 || x == 4) ? x : 2;
+    const int x = e ? atoi(e) : 0;
+    return (x == 1 || x == 2 || x == 4) ? x : 0;
   }();
-  return v;
+  return forced ? forced : (spp > 1 ? 1 : 2);
 }
 
 hipError_t launch_render_small(const RenderArgs &A, const SmallHost &hs, hipStream_t stream)
 {
   if (A.sc.ns + A.sc.nt > 64 || !A.utab || !A.vtab || hs.ns != A.sc.ns || hs.nt != A.sc.nt) return hipErrorInvalidValue;
-  switch (small_pixels_per_lane()) {
+  switch (small_pixels_per_lane(A.spp)) {
   case 1: return launch_small<1>(A, hs, stream);
   case 4: return launch_small<4>(A, hs, stream);
   default: return launch_small<2>(A, hs, stream);
