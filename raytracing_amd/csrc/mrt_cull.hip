@@ -230,6 +230,10 @@ __global__ __launch_bounds__(256) void render_cull_kernel(RenderArgs A)
         for (int p = 0; p < P; ++p) {
           const float rdn = dot3(dx[p], dy[p], dz[p], pnx, pny, pnz);
           const float t = num / rdn;
+          // the three edge tests only matter in lanes whose t is in range and could still win; no such lane
+          // in the wave (the triangle lies behind what the tile already hit, or behind the camera): skip them
+          const bool cand = (rdn != 0.0f) & (0.01f <= t) & (t <= best_t[p]);
+          if (!__any(cand)) continue;
           const float px = cam.ox + t * dx[p], py = cam.oy + t * dy[p], pz = cam.oz + t * dz[p];
           const float e0 = dot3(q[4], q[5], q[6], px, py, pz) - q[7];
           const float e1 = dot3(q[8], q[9], q[10], px, py, pz) - q[11];
@@ -434,6 +438,7 @@ __global__ __launch_bounds__(256) void render_cull_kernel(RenderArgs A)
               for (int p = 0; p < P; ++p) {
                 const float rdn = dot3(sdx[ix(p)], sdy[ix(p)], sdz[ix(p)], pnx, pny, pnz);
                 const float t = (kp - dot3(hpx[p], hpy[p], hpz[p], pnx, pny, pnz)) / rdn;
+                if (!__any(open[p] & (rdn != 0.0f) & (1e-3f <= t) & (t <= tl))) { still |= open[p]; continue; }
                 const float px = hpx[p] + t * sdx[ix(p)], py = hpy[p] + t * sdy[ix(p)], pz = hpz[p] + t * sdz[ix(p)];
                 const float e0 = dot3(q[4], q[5], q[6], px, py, pz) - q[7];
                 const float e1 = dot3(q[8], q[9], q[10], px, py, pz) - q[11];
