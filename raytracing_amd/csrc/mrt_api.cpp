@@ -360,7 +360,7 @@ static void tri_bound(const float q[16], float out[4])
     const double c1[3] = {r2[1] * r0[2] - r2[2] * r0[1], r2[2] * r0[0] - r2[0] * r0[2], r2[0] * r0[1] - r2[1] * r0[0]};
     const double c2[3] = {r0[1] * r1[2] - r0[2] * r1[1], r0[2] * r1[0] - r0[0] * r1[2], r0[0] * r1[1] - r0[1] * r1[0]};
     const double det = dot(r0, c0);
-    if (!(std::fabs(det) > 1e-9 * pl * nl[i] * nl[j])) return false;
+    if (!(std::fabs(det) > 1e-6 * pl * nl[i] * nl[j])) return false; // condition <= ~1e6: x is good to 1e-10 relative
     for (int a = 0; a < 3; ++a) x[a] = (a0 * c0[a] + a1 * c1[a] + a2 * c2[a]) / det;
     return std::isfinite(x[0]) && std::isfinite(x[1]) && std::isfinite(x[2]);
   };
@@ -370,20 +370,33 @@ static void tri_bound(const float q[16], float out[4])
     if (!solve(pi[e], pj[e], kp, k[pi[e]], k[pj[e]], V[e])) return;
     pmax = std::fmax(pmax, norm(V[e]));
   }
-  // bounded triangle <=> every vertex satisfies the third half-plane
+  // The three half-planes bound a triangle <=> every vertex lies strictly inside the third one.  The sign is
+  // what matters: with a vertex even 1e-8 (relative) on the wrong side, the region is an unbounded wedge -- the
+  // float edge planes of a sliver do that, and the hit test then accepts points tens of units from the geometric
+  // triangle.  Anything not clearly inside (1e-8 of the magnitudes, 100x the error of the solve) is "unbounded".
   for (int e = 0; e < 3; ++e) {
     const int m = pm[e];
-    if (!(dot(n[m], V[e]) - k[m] >= -1e-6 * (nl[m] * pmax + std::fabs(k[m]) + 1.0))) return;
+    if (!(dot(n[m], V[e]) - k[m] >= 1e-8 * (nl[m] * pmax + std::fabs(k[m])))) return;
   }
-  // push every edge plane outwards by the test's epsilon plus a bound on its fp32 evaluation error
-  const double pb = 1.5 * pmax + 1.0;
-  double kd[3];
-  for (int i = 0; i < 3; ++i) kd[i] = k[i] - (1e-6 + 2e-6 * (nl[i] * pb + std::fabs(k[i])));
+  // push every edge plane outwards by the test's epsilon plus a bound on its fp32 evaluation error at points of
+  // norm <= pb; a thin triangle grows a lot under that (by the push over the sine of its sharpest angle), so pb
+  // is raised until the pushed-out vertices lie within it
+  double pb = 1.5 * pmax + 1.0;
   double W[3][3], c[3] = {0, 0, 0};
-  for (int e = 0; e < 3; ++e) {
-    if (!solve(pi[e], pj[e], kp, kd[pi[e]], kd[pj[e]], W[e])) return;
-    for (int a = 0; a < 3; ++a) c[a] += W[e][a] / 3.0;
+  bool settled = false;
+  for (int round = 0; round < 6 && !settled; ++round) {
+    double kd[3], wmax = 0.0;
+    for (int i = 0; i < 3; ++i) kd[i] = k[i] - (1e-6 + 2e-6 * (nl[i] * pb + std::fabs(k[i])));
+    for (int e = 0; e < 3; ++e) {
+      if (!solve(pi[e], pj[e], kp, kd[pi[e]], kd[pj[e]], W[e])) return;
+      wmax = std::fmax(wmax, norm(W[e]));
+    }
+    if (wmax <= pb) settled = true;
+    else pb = 1.5 * wmax + 1.0;
   }
+  if (!settled) return;
+  for (int e = 0; e < 3; ++e)
+    for (int a = 0; a < 3; ++a) c[a] += W[e][a] / 3.0;
   double rad = 0.0;
   for (int e = 0; e < 3; ++e) {
     const double d[3] = {W[e][0] - c[0], W[e][1] - c[1], W[e][2] - c[2]};

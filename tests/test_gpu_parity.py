@@ -455,6 +455,21 @@ def test_random_small_scenes_vs_oracle(gpu_ctx, seed):
     assert_stats_parity(g["stats"], r["stats"])
 
 
+def test_sliver_with_open_edge_planes(gpu_ctx):
+    """Seed 516 of tools/stress_parity.py: a 0.02-unit sliver whose three float edge planes do not close, so the
+    exact test accepts it over a wedge tens of units long (714 pixels at 80x37).  Every culling kernel must see
+    it as unbounded (tests/test_host_layer.py has the bound itself)."""
+    spec = _random_small_scene(516)
+    gpu_ctx.upload(spec.flatten())
+    W, H = 80, 37
+    cam = spec.cam12(W / H)
+    g = gpu_ctx.render(cam, W, H)
+    r = O.Scene.from_spec(spec).render(cam, W, H, nthreads=8)
+    assert int((r["id"] == 26).sum()) > 500
+    assert_frame_parity(g, r, spec.name)
+    assert_stats_parity(g["stats"], r["stats"])
+
+
 
 # ------------------------------------------------------------------ mirror chains (max_depth > 0, SURVEY 8(f).1)
 

@@ -107,6 +107,32 @@ def test_cpp_host_layer_compiles_standalone(tmp_path):
                            str(src)])
 
 
+def test_triangle_bound_of_a_sliver_with_open_edge_planes_is_unbounded():
+    """A sliver whose float edge planes do not close: the pairwise intersection of edge planes 0 and 1 lies
+    1e-8 (relative) OUTSIDE edge plane 2, so the region the hit test accepts is an unbounded wedge and the
+    oracle accepts points more than 20 units from the geometric triangle (size 0.02).  The bound must be +inf.
+    Found by tools/stress_parity.py, seed 516."""
+    tri = np.array([[-6.747651, 12.751217, -2.9846556],
+                    [-6.737617, 12.738894, -2.9723556],
+                    [-6.7375774, 12.738748, -2.9724247]], np.float32)
+    t16 = capi.triangle_precompute(tri)[:, 0]
+    q = t16.astype(np.float64)
+    # a far point of the plane that all three edge tests accept (found by walking along the wedge)
+    n = q[:3] / np.linalg.norm(q[:3])
+    far_hits = 0
+    centre = tri.astype(np.float64).mean(0)
+    rng = np.random.default_rng(3)
+    for _ in range(4000):
+        dirn = rng.normal(size=3); dirn -= n * (n @ dirn); dirn /= np.linalg.norm(dirn)
+        pt = centre + dirn * 20.0
+        pt -= n * ((q[:3] @ pt - q[3]) / np.linalg.norm(q[:3]))
+        origin = (pt + n * 5.0).astype(np.float32)
+        ok, _, point, _ = O.triangle16_hit(t16, origin, (pt - origin).astype(np.float32), 0.01, float("inf"))
+        far_hits += bool(ok)
+    assert far_hits > 0, "the oracle should accept points 20 units from this sliver"
+    assert np.isinf(capi.triangle_bound(t16)[3])
+
+
 def test_triangle_bound_contains_every_accepted_point():
     """mrt_triangle_bound (host only): the ball the culling kernels use must contain every point the exact
     hit test (oracle) accepts.  Rays are shot at points inside and just outside the triangle; whenever the
