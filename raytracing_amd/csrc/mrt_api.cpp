@@ -342,54 +342,62 @@ static size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 // Unbounded, empty or ill-conditioned regions get radius +inf, i.e. are never culled.
 static void tri_bound(const float q[16], float out[4])
 {
+  typedef long double R; // x87 extended on the host: the sign decisions below need more than double at det ~ 1e-9
   out[0] = out[1] = out[2] = 0.0f;
   out[3] = INFINITY;
-  double pn[3] = {q[0], q[1], q[2]}, kp = q[3], n[3][3], k[3];
+  R pn[3] = {q[0], q[1], q[2]}, kp = q[3], n[3][3], k[3];
   for (int i = 0; i < 3; ++i) { n[i][0] = q[4 + 4 * i]; n[i][1] = q[5 + 4 * i]; n[i][2] = q[6 + 4 * i]; k[i] = q[7 + 4 * i]; }
-  auto norm = [](const double v[3]) { return std::sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]); };
-  auto dot = [](const double a[3], const double b[3]) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; };
+  auto norm = [](const R v[3]) { return sqrtl(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]); };
+  auto dot = [](const R a[3], const R b[3]) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; };
   for (int i = 0; i < 16; ++i) if (!std::isfinite(q[i])) return;
-  const double pl = norm(pn);
+  const R pl = norm(pn);
   if (!(pl > 1e-30)) return;
-  double nl[3];
+  R nl[3];
   for (int i = 0; i < 3; ++i) { nl[i] = norm(n[i]); if (!(nl[i] > 1e-30)) return; }
-  // x with pn.x = a0, n_i.x = a1, n_j.x = a2 (Cramer); false if the three planes are near-dependent
-  auto solve = [&](int i, int j, double a0, double a1, double a2, double x[3]) {
-    const double *r0 = pn, *r1 = n[i], *r2 = n[j];
-    const double c0[3] = {r1[1] * r2[2] - r1[2] * r2[1], r1[2] * r2[0] - r1[0] * r2[2], r1[0] * r2[1] - r1[1] * r2[0]};
-    const double c1[3] = {r2[1] * r0[2] - r2[2] * r0[1], r2[2] * r0[0] - r2[0] * r0[2], r2[0] * r0[1] - r2[1] * r0[0]};
-    const double c2[3] = {r0[1] * r1[2] - r0[2] * r1[1], r0[2] * r1[0] - r0[0] * r1[2], r0[0] * r1[1] - r0[1] * r1[0]};
-    const double det = dot(r0, c0);
-    if (!(std::fabs(det) > 1e-6 * pl * nl[i] * nl[j])) return false; // condition <= ~1e6: x is good to 1e-10 relative
+  // x with pn.x = a0, n_i.x = a1, n_j.x = a2 (Cramer); false if the three planes are near-dependent.  *rel is
+  // the determinant over the product of the row norms: x carries a relative error of a few 1e-19 / *rel
+  auto solve = [&](int i, int j, R a0, R a1, R a2, R x[3], R* rel) {
+    const R *r0 = pn, *r1 = n[i], *r2 = n[j];
+    const R c0[3] = {r1[1] * r2[2] - r1[2] * r2[1], r1[2] * r2[0] - r1[0] * r2[2], r1[0] * r2[1] - r1[1] * r2[0]};
+    const R c1[3] = {r2[1] * r0[2] - r2[2] * r0[1], r2[2] * r0[0] - r2[0] * r0[2], r2[0] * r0[1] - r2[1] * r0[0]};
+    const R c2[3] = {r0[1] * r1[2] - r0[2] * r1[1], r0[2] * r1[0] - r0[0] * r1[2], r0[0] * r1[1] - r0[1] * r1[0]};
+    const R det = dot(r0, c0);
+    if (!(fabsl(det) > 1e-9 * pl * nl[i] * nl[j])) return false;
+    *rel = fabsl(det) / (pl * nl[i] * nl[j]);
     for (int a = 0; a < 3; ++a) x[a] = (a0 * c0[a] + a1 * c1[a] + a2 * c2[a]) / det;
     return std::isfinite(x[0]) && std::isfinite(x[1]) && std::isfinite(x[2]);
   };
   const int pi[3] = {0, 1, 2}, pj[3] = {1, 2, 0}, pm[3] = {2, 0, 1};
-  double V[3][3], pmax = 0.0;
+  R V[3][3], vrel[3], pmax = 0.0;
   for (int e = 0; e < 3; ++e) {
-    if (!solve(pi[e], pj[e], kp, k[pi[e]], k[pj[e]], V[e])) return;
-    pmax = std::fmax(pmax, norm(V[e]));
+    if (!solve(pi[e], pj[e], kp, k[pi[e]], k[pj[e]], V[e], &vrel[e])) return;
+    pmax = fmaxl(pmax, norm(V[e]));
   }
   // The three half-planes bound a triangle <=> every vertex lies strictly inside the third one.  The sign is
   // what matters: with a vertex even 1e-8 (relative) on the wrong side, the region is an unbounded wedge -- the
   // float edge planes of a sliver do that, and the hit test then accepts points tens of units from the geometric
-  // triangle.  Anything not clearly inside (1e-8 of the magnitudes, 100x the error of the solve) is "unbounded".
+  // triangle.  Anything not clearly inside (by ~40x the error of the solve, and at least 1e-12 of the
+  // magnitudes) is "unbounded".  (Edge planes are dir x point_inside with a POSITION vector, so all three contain
+  // the direction of that position and the solve degrades as the triangle's plane nears the world origin: a
+  // terrain around y = 0 has determinants down to 1e-8, which is why the floor is tied to *rel and not fixed.)
   for (int e = 0; e < 3; ++e) {
     const int m = pm[e];
-    if (!(dot(n[m], V[e]) - k[m] >= 1e-8 * (nl[m] * pmax + std::fabs(k[m])))) return;
+    const R tol = fmaxl(1e-12L, 2e-17L / vrel[e]);
+    if (!(dot(n[m], V[e]) - k[m] >= tol * (nl[m] * pmax + fabsl(k[m])))) return;
   }
   // push every edge plane outwards by the test's epsilon plus a bound on its fp32 evaluation error at points of
   // norm <= pb; a thin triangle grows a lot under that (by the push over the sine of its sharpest angle), so pb
   // is raised until the pushed-out vertices lie within it
-  double pb = 1.5 * pmax + 1.0;
-  double W[3][3], c[3] = {0, 0, 0};
+  R pb = 1.5 * pmax + 1.0;
+  R W[3][3], c[3] = {0, 0, 0};
   bool settled = false;
   for (int round = 0; round < 6 && !settled; ++round) {
-    double kd[3], wmax = 0.0;
-    for (int i = 0; i < 3; ++i) kd[i] = k[i] - (1e-6 + 2e-6 * (nl[i] * pb + std::fabs(k[i])));
+    R kd[3], wmax = 0.0;
+    for (int i = 0; i < 3; ++i) kd[i] = k[i] - (1e-6 + 2e-6 * (nl[i] * pb + fabsl(k[i])));
     for (int e = 0; e < 3; ++e) {
-      if (!solve(pi[e], pj[e], kp, kd[pi[e]], kd[pj[e]], W[e])) return;
-      wmax = std::fmax(wmax, norm(W[e]));
+      R rel;
+      if (!solve(pi[e], pj[e], kp, kd[pi[e]], kd[pj[e]], W[e], &rel)) return;
+      wmax = fmaxl(wmax, norm(W[e]));
     }
     if (wmax <= pb) settled = true;
     else pb = 1.5 * wmax + 1.0;
@@ -397,13 +405,13 @@ static void tri_bound(const float q[16], float out[4])
   if (!settled) return;
   for (int e = 0; e < 3; ++e)
     for (int a = 0; a < 3; ++a) c[a] += W[e][a] / 3.0;
-  double rad = 0.0;
+  R rad = 0.0;
   for (int e = 0; e < 3; ++e) {
-    const double d[3] = {W[e][0] - c[0], W[e][1] - c[1], W[e][2] - c[2]};
-    rad = std::fmax(rad, norm(d));
+    const R d[3] = {W[e][0] - c[0], W[e][1] - c[1], W[e][2] - c[2]};
+    rad = fmaxl(rad, norm(d));
   }
   // hit points are float-rounded and only approximately on the plane
-  rad = (rad + 1e-5 * (pb + std::fabs(kp) / pl) + 1e-6 * norm(c)) * 1.0001;
+  rad = (rad + 1e-5 * (pb + fabsl(kp) / pl) + 1e-6 * norm(c)) * 1.0001;
   if (!std::isfinite(rad) || !(rad < 1e30)) return;
   out[0] = (float)c[0]; out[1] = (float)c[1]; out[2] = (float)c[2];
   out[3] = std::nextafter((float)rad, INFINITY);
