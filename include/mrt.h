@@ -100,9 +100,10 @@ typedef struct mrt_partition {
 typedef struct mrt_render_params {
   int32_t width, height;  /* full frame */
   int32_t spp;            /* 1: one sample at (col/W,row/H); 121: rt::MultisampleMesh (pipeline/multisample_mesh.cuh) */
-  int32_t max_depth;      /* config::MAX_RECURSION_DEPTH (src/main.cu:26); 0 = primary + shadow; 1..8 = mirror
-                             chains (src/main.cu:79-98), accepted only when every material is metallic:
-                             a diffuse bounce draws from cuRAND (core/material.cuh:52-61), not implemented */
+  int32_t max_depth;      /* config::MAX_RECURSION_DEPTH (src/main.cu:26; the reference is built with 8);
+                             0 = primary + shadow; 1..8 = bounce chains (src/main.cu:79-98): metallic surfaces
+                             mirror, diffuse ones draw the bounce from the pixel's XORWOW stream
+                             (core/material.cuh:52-61, cuda_utils/curand_state.cuh:15-23; MRT_OPT_RNG_SEED) */
   mrt_partition part;
 } mrt_render_params;
 
@@ -125,12 +126,15 @@ const char *mrt_last_error(const mrt_ctx *ctx);
 const char *mrt_status_string(int status);
 
 /*
- * Context options (no reference counterpart).  MRT_OPT_CULL (default 1, or environment MRT_CULL) picks the
+ * Context options.  MRT_OPT_CULL (no reference counterpart; default 1, or environment MRT_CULL) picks the
  * render kernel: 0 = brute force, which like the reference loops (src/main.cu:67-77) tests every ray against
  * every primitive; 1 = automatic; 2 = one-level tile culling; 3 / 4 = two-level tile culling with 4 / 8 waves
- * per workgroup.  All kernels produce identical buffers.
+ * per workgroup; 5 = the small-scene kernel (at most 64 primitives, else 2).  All kernels produce identical
+ * buffers.  MRT_OPT_RNG_SEED (default 1984, the constant of cuda_utils/curand_state.cuh:22; 0..2^31-1) seeds
+ * the per-pixel random streams of diffuse bounces: pixel i of the full frame owns subsequence i, like
+ * curand_init(seed, i, 0, ...).
  */
-enum { MRT_OPT_CULL = 1 };
+enum { MRT_OPT_CULL = 1, MRT_OPT_RNG_SEED = 2 };
 int mrt_ctx_set_option(mrt_ctx *ctx, int option, int value);
 
 /*
@@ -138,6 +142,12 @@ int mrt_ctx_set_option(mrt_ctx *ctx, int option, int value);
  * kernels use for one triangle given in the 16-float precomputed form.  Radius +inf = never culled.
  */
 int mrt_triangle_bound(const float tri16[16], float out4[4]);
+
+/*
+ * Host-only diagnostic (no GPU, no context): the XORWOW state curand_init(seed, subsequence, 0, &state) leaves
+ * (cuda_utils/curand_state.cuh:22), as the library computes it: out6 = xorshift words v[0..4], Weyl counter d.
+ */
+int mrt_rng_state(uint64_t seed, uint32_t subsequence, uint32_t out6[6]);
 
 /* --- scene: replaces cudaMallocManaged-backed rt::Vector (container/vector.cuh:26,131) */
 int mrt_scene_upload(mrt_ctx *ctx, const mrt_scene_desc *scene);

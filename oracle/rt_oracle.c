@@ -72,6 +72,7 @@ typedef struct { int kind; v3 v; v3 color; } light_t;   /* v = dir_ (normalised)
 struct orc_scene {
   object_t *obj; int nobj, cap_obj;
   light_t *light; int nlight, cap_light;
+  uint64_t rng_seed; /* cuda_utils/curand_state.cuh:22: 1984 */
 };
 
 /* ------------------------------------------------------------------ geometry */
@@ -174,6 +175,163 @@ static int object_hit(const object_t *o, const ray_t *r, interval_t I, hit_t *ou
   }
 }
 
+/* ------------------------------------------------------------------ random numbers */
+
+/*
+ * The reference draws from cuRAND's default generator (curandState = XORWOW), one state per pixel set up by
+ * curand_init(1984, pixel_index, 0, &state) (cuda_utils/curand_state.cuh:15-23).  cuRAND is a closed library
+ * that is absent here; this restates its PUBLISHED algorithm (curand_kernel.h, CUDA toolkit):
+ *   - Marsaglia's xorwow: five 32-bit xorshift words v[0..4] and a Weyl counter d stepping by 362437,
+ *     output v[4] + d;
+ *   - seeding: s0 = lo32(seed) ^ 0xaad26b49, s1 = hi32(seed) ^ 0xf7dcefdd, t0 = 1099087573 s0,
+ *     t1 = 2591861531 s1; d = 6615241 + t1 + t0; v = {123456789 + t0, 362436069 ^ t0, 521288629 + t1,
+ *     88675123 ^ t1, 5783321 + t0};
+ *   - subsequence n starts n * 2^67 steps into the stream.  The xorshift part is linear over GF(2), so the
+ *     jump is the 160x160 bit matrix A^(n 2^67) applied to v; d moves by 362437 n 2^67 = 0 (mod 2^32);
+ *   - curand_uniform: x * 2^-32 + 2^-33 in fp32, x converted to float first: (0, 1].  (2^-32 is a power of
+ *     two, so the product is exact and a fused multiply-add gives the same float.)
+ * No cuRAND output vector exists in this image: parity with cuRAND's streams is UNPINNED.  What the tests
+ * pin: A^(2^67) computed here by squaring equals rocRAND's precomputed table (rocrand_xorwow_precomputed.h,
+ * a second implementation of the same recurrence and jump), small jumps equal stepping, and the GPU path
+ * equals this restatement bit for bit.
+ */
+typedef struct { uint32_t v[5]; uint32_t d; } xorwow_t;
+
+static inline uint32_t xorwow_next(xorwow_t *g)
+{
+  uint32_t t = g->v[0] ^ (g->v[0] >> 2);
+  g->v[0] = g->v[1]; g->v[1] = g->v[2]; g->v[2] = g->v[3]; g->v[3] = g->v[4];
+  g->v[4] = (g->v[4] ^ (g->v[4] << 4)) ^ (t ^ (t << 1));
+  g->d += 362437u;
+  return g->v[4] + g->d;
+}
+
+static inline float xorwow_uniform(xorwow_t *g)
+{
+  return (float)xorwow_next(g) * 2.3283064e-10f + (2.3283064e-10f / 2.0f);
+}
+
+/* bit matrices: row (w*32 + j) = image of the state with only bit j of word w set */
+typedef struct { uint32_t row[160][5]; } bitmat_t;
+
+static void bitmat_apply(const bitmat_t *m, const uint32_t in[5], uint32_t out[5])
+{
+  uint32_t r[5] = {0, 0, 0, 0, 0};
+  for (int w = 0; w < 5; ++w)
+    for (int j = 0; j < 32; ++j)
+      if ((in[w] >> j) & 1u)
+        for (int k = 0; k < 5; ++k) r[k] ^= m->row[w * 32 + j][k];
+  memcpy(out, r, sizeof r);
+}
+
+static void bitmat_step(bitmat_t *m) /* A: one xorwow step */
+{
+  for (int w = 0; w < 5; ++w)
+    for (int j = 0; j < 32; ++j) {
+      xorwow_t g;
+      memset(&g, 0, sizeof g);
+      g.v[w] = 1u << j;
+      (void)xorwow_next(&g);
+      memcpy(m->row[w * 32 + j], g.v, sizeof g.v);
+    }
+}
+
+static void bitmat_square(bitmat_t *m)
+{
+  bitmat_t *sq = (bitmat_t *)malloc(sizeof *sq);
+  for (int r = 0; r < 160; ++r) bitmat_apply(m, m->row[r], sq->row[r]);
+  *m = *sq;
+  free(sq);
+}
+
+/* A^(2^log2) */
+static void bitmat_pow2(int log2, bitmat_t *m)
+{
+  bitmat_step(m);
+  for (int i = 0; i < log2; ++i) bitmat_square(m);
+}
+
+static bitmat_t *g_seq_jump;     /* [64]: A^(2^(67+b)) */
+static pthread_once_t g_seq_once = PTHREAD_ONCE_INIT;
+static void seq_jump_build(void)
+{
+  g_seq_jump = (bitmat_t *)malloc(64 * sizeof(bitmat_t));
+  bitmat_pow2(67, &g_seq_jump[0]);
+  for (int b = 1; b < 64; ++b) { g_seq_jump[b] = g_seq_jump[b - 1]; bitmat_square(&g_seq_jump[b]); }
+}
+
+/* curand_init(seed, subsequence, 0, state) */
+static void xorwow_init(uint64_t seed, uint64_t subsequence, xorwow_t *g)
+{
+  uint32_t s0 = (uint32_t)seed ^ 0xaad26b49u, s1 = (uint32_t)(seed >> 32) ^ 0xf7dcefddu;
+  uint32_t t0 = 1099087573u * s0, t1 = 2591861531u * s1;
+  g->d = 6615241u + t1 + t0;
+  g->v[0] = 123456789u + t0;
+  g->v[1] = 362436069u ^ t0;
+  g->v[2] = 521288629u + t1;
+  g->v[3] = 88675123u ^ t1;
+  g->v[4] = 5783321u + t0;
+  pthread_once(&g_seq_once, seq_jump_build);
+  for (int b = 0; b < 64; ++b)
+    if ((subsequence >> b) & 1u) bitmat_apply(&g_seq_jump[b], g->v, g->v);
+}
+
+void orc_xorwow_init(uint64_t seed, uint64_t subsequence, uint32_t state6[6])
+{
+  xorwow_t g;
+  xorwow_init(seed, subsequence, &g);
+  memcpy(state6, g.v, sizeof g.v);
+  state6[5] = g.d;
+}
+
+void orc_xorwow_draw(uint32_t state6[6], int n, uint32_t *raw, float *uniform)
+{
+  xorwow_t g;
+  memcpy(g.v, state6, sizeof g.v);
+  g.d = state6[5];
+  for (int i = 0; i < n; ++i) {
+    xorwow_t before = g;
+    uint32_t x = xorwow_next(&g);
+    if (raw) raw[i] = x;
+    if (uniform) { g = before; uniform[i] = xorwow_uniform(&g); }
+  }
+  memcpy(state6, g.v, sizeof g.v);
+  state6[5] = g.d;
+}
+
+void orc_xorwow_pow2_matrix(int log2, uint32_t out800[800])
+{
+  bitmat_t *m = (bitmat_t *)malloc(sizeof *m);
+  bitmat_pow2(log2, m);
+  memcpy(out800, m->row, sizeof m->row);
+  free(m);
+}
+
+/* cuda_utils/curand_state.cuh:85-90: three draws (taken in x, y, z order -- C++ leaves the order of
+ * constructor arguments to the compiler; unpinned like the streams themselves) */
+static v3 random_vector(xorwow_t *g)
+{
+  float x = xorwow_uniform(g);
+  float y = xorwow_uniform(g);
+  float z = xorwow_uniform(g);
+  return v3_make(x, y, z);
+}
+
+/* cuda_utils/curand_state.cuh:93-109.  The vector is tested against the unit ball around (0.5,0.5,0.5) but
+ * returned UNcentred, in (0,1]^3; the test can never fail there (at most 0.75 <= 1), so a bounce costs
+ * exactly three draws.  The loop is kept as the reference has it. */
+static v3 random_in_unit_sphere(xorwow_t *g)
+{
+  const v3 centre = v3_make(0.5f, 0.5f, 0.5f);
+  v3 v = random_vector(g);
+  for (;;) {
+    v3 vc = v3_sub(v, centre);
+    if (v3_dot(vc, vc) <= 1.0f) break;
+    v = random_vector(g);
+  }
+  return v;
+}
+
 /* ------------------------------------------------------------------ materials */
 
 /* core/material.cuh:151-158 (direction only; origin is irrelevant to callers here) */
@@ -257,7 +415,7 @@ static int light_color(const orc_scene *s, const hit_t *hit, int hit_index, cons
 /* src/main.cu:44-105.  max_depth plays config::MAX_RECURSION_DEPTH.
  * *id_out / *t_out get the depth-0 closest hit. */
 static v3 color_ray(const orc_scene *s, const ray_t *r, int depth, int max_depth, int32_t *id_out, float *t_out,
-                    orc_stats *st)
+                    orc_stats *st, xorwow_t *rng)
 {
   if (depth > max_depth) return v3_make(0.01f, 0.01f, 0.01f);
 
@@ -281,19 +439,22 @@ static v3 color_ray(const orc_scene *s, const ray_t *r, int depth, int max_depth
   if (have_hit) {
     if (depth == 0) st->hit_pixels++;
     const object_t *o = &s->obj[hit_index];
+    /* src/main.cu:80-83: the bounce comes first and a diffuse one advances the pixel's random stream
+     * (core/material.cuh:52-61), also at the last level, whose bounce ray is never followed.  With
+     * max_depth == 0 no level is ever followed and no stream is set up: rng is NULL there. */
+    ray_t bounce;
+    bounce.o = best.point;
+    if (o->mat_kind == ORC_MAT_DIFFUSE) {
+      if (rng) bounce.d = v3_add(best.normal, random_in_unit_sphere(rng));
+      else bounce.d = best.normal;
+    } else {
+      bounce.d = metallic_reflect(r->d, best.normal); /* core/material.cuh:126-132 */
+    }
     v3 light = v3_make(0, 0, 0);
     int have_light = light_color(s, &best, hit_index, r, &light, st);
 
-    v3 incoming;
-    if (depth + 1 > max_depth) {
-      incoming = v3_make(0.01f, 0.01f, 0.01f); /* what the recursive call returns, src/main.cu:51-53 */
-    } else {
-      /* only mirror chains are deterministic (core/material.cuh:126-132); diffuse needs the RNG */
-      ray_t bounce;
-      bounce.o = best.point;
-      bounce.d = metallic_reflect(r->d, best.normal);
-      incoming = color_ray(s, &bounce, depth + 1, max_depth, 0, 0, st);
-    }
+    /* beyond the limit the recursive call returns 0.01 at once, src/main.cu:51-53 */
+    v3 incoming = color_ray(s, &bounce, depth + 1, max_depth, 0, 0, st, rng);
     if (have_light) return v3_add(material_color_fn(o->color, incoming), material_color_fn(o->color, light));
     return material_color_fn(o->color, incoming);
   }
@@ -355,7 +516,7 @@ static void msmesh_offsets(float norm_x, float norm_y, float off[MS_W * MS_H][2]
 /* ------------------------------------------------------------------ render */
 
 typedef struct {
-  const orc_scene *s; const float *cam; int W, H, row_begin, row_end, spp, max_depth;
+  const orc_scene *s; const float *cam; int W, H, row_begin, row_end, spp, max_depth, any_diffuse;
   float *rgb; int32_t *id; float *t; orc_stats st;
 } job_t;
 
@@ -374,12 +535,15 @@ static void render_rows(job_t *j)
       float v = (float)row / (float)j->H;
       v3 acc = v3_make(0.0f, 0.0f, 0.0f);
       int32_t id = -1; float t = INFINITY;
+      /* src/main.cu:133-135: a private copy of the pixel's state, shared by all of its samples */
+      xorwow_t rng_state, *rng = 0;
+      if (j->max_depth > 0 && j->any_diffuse) { xorwow_init(j->s->rng_seed, (uint64_t)pix, &rng_state); rng = &rng_state; }
       for (int sidx = 0; sidx < nsamp; ++sidx) {
         float su = u, sv = v;
         if (nsamp > 1) { su = u + off[sidx][0]; sv = v + off[sidx][1]; }
         ray_t ray = compute_ray(j->cam, su, sv);
         j->st.primary_rays++;
-        acc = v3_add(acc, color_ray(j->s, &ray, 0, j->max_depth, &id, &t, &j->st));
+        acc = v3_add(acc, color_ray(j->s, &ray, 0, j->max_depth, &id, &t, &j->st, rng));
       }
       acc = v3_div(acc, (float)nsamp);
       if (j->rgb) v3_to(acc, j->rgb + 3 * pix);
@@ -397,10 +561,9 @@ int orc_render(const orc_scene *s, const float cam12[12], int W, int H, int row_
   if (!s || !cam12 || W <= 0 || H <= 0 || row_begin < 0 || row_end > H || row_begin > row_end) return -1;
   if (spp != 1 && spp != MS_W * MS_H) return -1;
   if (max_depth < 0) return -1;
-  if (max_depth > 0) {
-    for (int i = 0; i < s->nobj; ++i)
-      if (s->obj[i].mat_kind == ORC_MAT_DIFFUSE) return -2; /* diffuse bounce needs the RNG: not restated */
-  }
+  int any_diffuse = 0;
+  for (int i = 0; i < s->nobj; ++i)
+    if (s->obj[i].mat_kind == ORC_MAT_DIFFUSE) any_diffuse = 1;
   if (nthreads < 1) nthreads = 1;
   int rows = row_end - row_begin;
   if (nthreads > rows) nthreads = rows > 0 ? rows : 1;
@@ -414,7 +577,7 @@ int orc_render(const orc_scene *s, const float cam12[12], int W, int H, int row_
     jobs[k].s = s; jobs[k].cam = cam12; jobs[k].W = W; jobs[k].H = H;
     jobs[k].row_begin = row_begin + (int)((long long)rows * k / nthreads);
     jobs[k].row_end = row_begin + (int)((long long)rows * (k + 1) / nthreads);
-    jobs[k].spp = spp; jobs[k].max_depth = max_depth;
+    jobs[k].spp = spp; jobs[k].max_depth = max_depth; jobs[k].any_diffuse = any_diffuse;
     jobs[k].rgb = rgb; jobs[k].id = id; jobs[k].t = t;
   }
   if (nthreads == 1) {
@@ -439,7 +602,14 @@ int orc_render(const orc_scene *s, const float cam12[12], int W, int H, int row_
 
 /* ------------------------------------------------------------------ scene building */
 
-orc_scene *orc_scene_create(void) { return (orc_scene *)calloc(1, sizeof(orc_scene)); }
+orc_scene *orc_scene_create(void)
+{
+  orc_scene *s = (orc_scene *)calloc(1, sizeof(orc_scene));
+  if (s) s->rng_seed = 1984; /* cuda_utils/curand_state.cuh:22 */
+  return s;
+}
+
+void orc_scene_set_rng_seed(orc_scene *s, uint64_t seed) { s->rng_seed = seed; }
 
 void orc_scene_destroy(orc_scene *s)
 {

@@ -95,14 +95,24 @@ int orc_triangle16_hit(const float tri16[16], const float ro[3], const float rd[
 
 /* Render rows [row_begin,row_end) of a W x H frame (src/main.cu:132-156 per pixel).
  * spp: 1 = single sample at (u,v), 121 = MultisampleMesh.
- * max_depth: value of config::MAX_RECURSION_DEPTH (src/main.cu:26); only 0 is
- * supported with diffuse objects (deeper needs the RNG); mirror-only chains are
- * followed for max_depth > 0 when every bounce lands on metallic surfaces.
+ * max_depth: value of config::MAX_RECURSION_DEPTH (src/main.cu:26), 0..8 here.  With max_depth > 0 a
+ * diffuse hit bounces along normal + random vector drawn from the pixel's XORWOW stream
+ * (seed orc_scene_set_rng_seed, default 1984; subsequence = row*W + col), a metallic one mirrors.
  * Outputs are full-frame arrays (W*H*3 / W*H / W*H), row 0 = v 0; any may be NULL.
  * id = object index of the closest hit of the (last) sample, -1 on miss; t = +inf on miss.
  * nthreads <= 1 runs on the calling thread. */
 int orc_render(const orc_scene *s, const float cam12[12], int W, int H, int row_begin, int row_end, int spp,
                int max_depth, int nthreads, float *rgb, int32_t *id, float *t, orc_stats *stats);
+
+/* --- the random streams of the diffuse bounce (cuda_utils/curand_state.cuh:15-23, :85-109): cuRAND's XORWOW
+ * restated from its published algorithm; parity with cuRAND's own output is unpinned (see rt_oracle.c). */
+void orc_scene_set_rng_seed(orc_scene *s, uint64_t seed);
+/* curand_init(seed, subsequence, 0): state6 = v[0..4], d */
+void orc_xorwow_init(uint64_t seed, uint64_t subsequence, uint32_t state6[6]);
+/* n draws from state6 (advanced in place): raw 32-bit outputs and/or curand_uniform floats; either may be NULL */
+void orc_xorwow_draw(uint32_t state6[6], int n, uint32_t *raw, float *uniform);
+/* A^(2^log2) as 160 rows of 5 words, row (w*32 + j) = image of bit j of word w */
+void orc_xorwow_pow2_matrix(int log2, uint32_t out800[800]);
 
 #ifdef __cplusplus
 }

@@ -19,7 +19,7 @@ LIGHT_DIRECTIONAL, LIGHT_POINT = 0, 1
 # every symbol include/mrt.h declares (tests check the library exports all of them)
 MRT_SYMBOLS = [
     "mrt_device_count", "mrt_ctx_create", "mrt_ctx_destroy", "mrt_ctx_set_option", "mrt_last_error", "mrt_status_string",
-    "mrt_triangle_bound", "mrt_scene_upload", "mrt_local_rows", "mrt_render", "mrt_render_device", "mrt_assemble_strips",
+    "mrt_triangle_bound", "mrt_rng_state", "mrt_scene_upload", "mrt_local_rows", "mrt_render", "mrt_render_device", "mrt_assemble_strips",
     "mrt_intersect",
 ]
 
@@ -99,6 +99,7 @@ def libmrt():
         L.mrt_status_string.restype = C.c_char_p
         L.mrt_scene_upload.argtypes = [C.c_void_p, C.POINTER(SceneDesc)]
         L.mrt_triangle_bound.argtypes = [_f, _f]
+        L.mrt_rng_state.argtypes = [C.c_uint64, C.c_uint32, C.c_void_p]
         L.mrt_local_rows.argtypes = [C.c_int32, C.POINTER(Partition), _i32]
         L.mrt_render.argtypes = [C.c_void_p, C.POINTER(Camera), C.POINTER(RenderParams), C.c_void_p, C.c_void_p,
                                  C.c_void_p, C.POINTER(Stats)]
@@ -165,6 +166,16 @@ def triangle_bound(tri16):
     rc = libmrt().mrt_triangle_bound(_fp(q), _fp(out))
     if rc != 0:
         raise MrtError(f"mrt_triangle_bound: {rc}")
+    return out
+
+
+def rng_state(seed, subsequence):
+    """XORWOW state after curand_init(seed, subsequence, 0) as the library computes it (host-only diagnostic):
+    uint32[6] = xorshift words v[0..4], Weyl counter d."""
+    out = np.zeros(6, dtype=np.uint32)
+    rc = libmrt().mrt_rng_state(int(seed), int(subsequence), out.ctypes.data)
+    if rc != 0:
+        raise MrtError(f"mrt_rng_state: {rc}")
     return out
 
 
@@ -312,10 +323,14 @@ class Context:
 
     def set_cull(self, mode):
         """Render kernel: 0/False brute force, 1/True automatic (default), 2 one-level culling,
-        3 / 4 two-level culling with 4 / 8 waves.  Identical outputs."""
+        3 / 4 two-level culling with 4 / 8 waves, 5 the small-scene kernel.  Identical outputs."""
         mode = int(mode)
         self._check(self._L.mrt_ctx_set_option(self._h, 1, mode), "mrt_ctx_set_option")
         self.cull = mode
+
+    def set_rng_seed(self, seed):
+        """Seed of the per-pixel random streams of diffuse bounces (default 1984, as the reference)."""
+        self._check(self._L.mrt_ctx_set_option(self._h, 2, int(seed)), "mrt_ctx_set_option")
 
     def upload(self, flat):
         d = flat.desc()

@@ -29,7 +29,7 @@ struct mrt_ctx {
   size_t scene_bytes = 0;
   mrt::DevScene sc{};
   bool have_scene = false;
-  bool any_diffuse = false; // mirror chains (max_depth > 0) need an all-metallic scene
+  bool any_diffuse = false; // bounce chains (max_depth > 0) over a diffuse object need the random streams below
 
   // output staging for the blocking host-buffer entry point
   void *out_mem = nullptr;
@@ -44,6 +44,13 @@ struct mrt_ctx {
   // launcher derives the camera-dependent culling functions from it for every render
   std::vector<float> small_tri16, small_sph;
   std::vector<int32_t> small_tri_obj, small_sph_obj;
+
+  // per-pixel XORWOW streams of the diffuse bounce (mrt_rng.hip): jump matrices, and the xorshift words of
+  // streams 0..rng_n-1 for seed rng_seed (5 streams of rng_n words), built on first need
+  uint32_t *rng_jump = nullptr;
+  uint32_t *rng_mem = nullptr;
+  uint32_t rng_n = 0;
+  uint64_t rng_seed = 1984, rng_built_seed = 0; // cuda_utils/curand_state.cuh:22
 };
 
 static thread_local std::string g_create_err;
@@ -101,9 +108,45 @@ static hipError_t ensure_uv_tables(mrt_ctx *ctx, int W, int H, hipStream_t st)
   return hipSuccess;
 }
 
+// Streams 0..npix-1 (the stream of a pixel is its index in the FULL frame, src/main.cu:133, whatever strip
+// partition renders it).  Built on the context's stream and synchronised once, like the u/v tables.
+static hipError_t ensure_rng_states(mrt_ctx *ctx, size_t npix)
+{
+  if (ctx->rng_mem && ctx->rng_n >= npix && ctx->rng_built_seed == ctx->rng_seed) return hipSuccess;
+  hipError_t e;
+  if (!ctx->rng_jump) {
+    const size_t bytes = (size_t)mrt::RNG_JUMP_MATRICES * 800 * sizeof(uint32_t);
+    if ((e = hipMalloc((void **)&ctx->rng_jump, bytes)) != hipSuccess) return e;
+    if ((e = hipMemcpy(ctx->rng_jump, mrt::rng_jump_tables(), bytes, hipMemcpyHostToDevice)) != hipSuccess) return e;
+  }
+  if (ctx->rng_n < npix) {
+    if (ctx->rng_mem) {
+      if ((e = hipDeviceSynchronize()) != hipSuccess) return e; // a render in flight may still read the old buffer
+      (void)hipFree(ctx->rng_mem);
+      ctx->rng_mem = nullptr; ctx->rng_n = 0;
+    }
+    const size_t n = (npix + 1023) / 1024 * 1024;
+    if ((e = hipMalloc((void **)&ctx->rng_mem, 5 * n * sizeof(uint32_t))) != hipSuccess) return e;
+    ctx->rng_n = (uint32_t)n;
+  } else if ((e = hipDeviceSynchronize()) != hipSuccess) return e; // new seed: same buffer, rebuilt
+  if ((e = mrt::launch_rng_init(ctx->rng_jump, ctx->rng_mem, ctx->rng_n, ctx->rng_n, ctx->rng_seed, ctx->stream)) != hipSuccess) return e;
+  if ((e = hipStreamSynchronize(ctx->stream)) != hipSuccess) return e;
+  ctx->rng_built_seed = ctx->rng_seed;
+  return hipSuccess;
+}
+
 static hipError_t launch_by_mode(mrt_ctx *ctx, mrt::RenderArgs &A, hipStream_t st)
 {
-  if (A.max_depth > 0) return mrt::launch_render_bounce(A, st); // mirror chains: one kernel, every ray x every primitive
+  if (A.max_depth > 0) { // bounce chains: one kernel, every ray x every primitive
+    if (ctx->any_diffuse) {
+      hipError_t e = ensure_rng_states(ctx, (size_t)A.W * A.H);
+      if (e != hipSuccess) return e;
+      uint32_t v[5];
+      mrt::rng_seed_state(ctx->rng_seed, v, &A.rng_d);
+      A.rng = ctx->rng_mem; A.rng_stride = ctx->rng_n;
+    }
+    return mrt::launch_render_bounce(A, st);
+  }
   int mode = ctx->cull;
   const bool small = (long)A.sc.ns + A.sc.nt <= 64;
   // measured: the small-scene kernel wins where it applies; with the primitive-side hierarchy the
@@ -263,6 +306,11 @@ int mrt_ctx_set_option(mrt_ctx *ctx, int option, int value)
     ctx->cull = value;
     return MRT_OK;
   }
+  if (option == MRT_OPT_RNG_SEED) {
+    if (value < 0) return fail(ctx, MRT_ERR_INVALID, "MRT_OPT_RNG_SEED takes 0..2^31-1");
+    ctx->rng_seed = (uint64_t)value;
+    return MRT_OK;
+  }
   return fail(ctx, MRT_ERR_INVALID, "unknown option");
 }
 
@@ -324,6 +372,8 @@ int mrt_ctx_destroy(mrt_ctx *ctx)
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
   if (ctx->scene_mem) (void)hipFree(ctx->scene_mem);
   if (ctx->uv_mem) (void)hipFree(ctx->uv_mem);
+  if (ctx->rng_mem) (void)hipFree(ctx->rng_mem);
+  if (ctx->rng_jump) (void)hipFree(ctx->rng_jump);
   if (ctx->out_mem) (void)hipFree(ctx->out_mem);
   if (ctx->stats_dev) (void)hipFree(ctx->stats_dev);
   if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
@@ -478,6 +528,13 @@ static void shadow_functions(const float q[16], int kind, const float lv[3], flo
     out[7 * i + 4] = up(n1f(g));
     out[7 * i + 5] = up(a); out[7 * i + 6] = up(b);
   }
+}
+
+int mrt_rng_state(uint64_t seed, uint32_t subsequence, uint32_t out6[6])
+{
+  if (!out6) return MRT_ERR_INVALID;
+  mrt::rng_host_state(seed, subsequence, out6);
+  return MRT_OK;
 }
 
 int mrt_triangle_bound(const float tri16[16], float out4[4])
@@ -662,8 +719,8 @@ static int fill_args(mrt_ctx *ctx, const mrt_camera *cam, const mrt_render_param
   if (p->width > 65536 || p->height > 65536) return fail(ctx, MRT_ERR_TOO_LARGE, "frame larger than 65536 in a dimension");
   if (p->spp != 1 && p->spp != 121) return fail(ctx, MRT_ERR_INVALID, "spp must be 1 or 121");
   if (p->max_depth < 0 || p->max_depth > 8) return fail(ctx, MRT_ERR_INVALID, "max_depth must be 0..8");
-  if (p->max_depth > 0 && ctx->any_diffuse)
-    return fail(ctx, MRT_ERR_INVALID, "max_depth > 0 needs an all-metallic scene (diffuse bounces draw random numbers: not implemented)");
+  if (p->max_depth > 0 && ctx->any_diffuse && (uint64_t)p->width * (uint64_t)p->height > ((uint64_t)1 << 28))
+    return fail(ctx, MRT_ERR_TOO_LARGE, "diffuse bounces: more than 2^28 pixels (one random stream of 20 bytes per pixel)");
   if (!partition_ok(p->part)) return fail(ctx, MRT_ERR_INVALID, "bad strip partition");
   std::memset(&A, 0, sizeof A);
   A.sc = ctx->sc;

@@ -1,7 +1,9 @@
-// mrt_bounce.hip -- mirror chains: config::MAX_RECURSION_DEPTH > 0 (src/main.cu:26, :79-98) for scenes whose
-// materials are all metallic.  MetallicMaterial::bounce is deterministic
-// (core/material.cuh:126-132, :151-158); DiffuseMaterial::bounce draws from the per-pixel cuRAND state and is
-// the next row (8(f).2): the C-ABI refuses max_depth > 0 for scenes with a diffuse object.
+// mrt_bounce.hip -- bounce chains: config::MAX_RECURSION_DEPTH > 0 (src/main.cu:26, :79-98).
+// MetallicMaterial::bounce mirrors the ray (core/material.cuh:126-132, :151-158); DiffuseMaterial::bounce sends
+// it along normal + a random vector of (0,1]^3 drawn from the pixel's XORWOW stream (core/material.cuh:52-61,
+// cuda_utils/curand_state.cuh:85-109; streams: mrt_rng.hip).  The stream belongs to the pixel, not the sample:
+// the 121 samples of a pixel draw from it one after the other (src/main.cu:135, :149-153), so the sample loop
+// below must stay sequential per lane.
 //
 // The reference recurses: color_ray(depth) = C (.) color_ray(depth + 1) [+ C (.) light].  Here the chain is
 // walked iteratively (the reference's TODO.md asks for exactly that): every level pushes its object colour and
@@ -46,6 +48,21 @@ __global__ __launch_bounds__(256) void render_bounce_kernel(RenderArgs A)
   const int nsamp = A.spp;
   const float DIVW = 13.0f, DIVH = 13.0f;
   const float v = float(grow) / float(A.H); // src/main.cu:137
+
+  // src/main.cu:133-135: a private copy of the pixel's state; never written back
+  const bool use_rng = A.rng != nullptr;
+  uint32_t g0 = 0, g1 = 0, g2 = 0, g3 = 0, g4 = 0, gd = A.rng_d;
+  if (use_rng && valid) {
+    const size_t pi = size_t(grow) * A.W + col, rs = A.rng_stride;
+    g0 = A.rng[pi]; g1 = A.rng[rs + pi]; g2 = A.rng[2 * rs + pi]; g3 = A.rng[3 * rs + pi]; g4 = A.rng[4 * rs + pi];
+  }
+  auto uniform = [&]() -> float { // curand_uniform: xorwow draw, then x * 2^-32 + 2^-33
+    const uint32_t tt = g0 ^ (g0 >> 2);
+    g0 = g1; g1 = g2; g2 = g3; g3 = g4;
+    g4 = (g4 ^ (g4 << 4)) ^ (tt ^ (tt << 1));
+    gd += 362437u;
+    return float(g4 + gd) * 2.3283064e-10f + (2.3283064e-10f / 2.0f);
+  };
 
   for (int sidx = 0; sidx < nsamp; ++sidx) {
     float offx = 0.0f, offy = 0.0f;
@@ -201,20 +218,36 @@ __global__ __launch_bounds__(256) void render_bounce_kernel(RenderArgs A)
         }
       }
 
-      // ---- push the level; continue with the mirrored ray or end the chain ----
+      // ---- push the level; continue with the bounced ray or end the chain ----
       if (have_hit) {
         const float *m = sc.mat_rgb + 3 * best_obj;
         stC[depth][0] = m[0]; stC[depth][1] = m[1]; stC[depth][2] = m[2];
         stL[depth][0] = lr; stL[depth][1] = lg; stL[depth][2] = lb;
         stH[depth] = have_light;
+        // the bounce (src/main.cu:80-83) happens at every level, the last one included: a diffuse surface
+        // advances the pixel's stream even when its bounce ray is never followed
+        float bdx, bdy, bdz;
+        if (use_rng && sc.mat_kind[best_obj] == 0) { // DiffuseMaterial::bounce, core/material.cuh:52-61
+          float rx = uniform(), ry = uniform(), rz = uniform();
+          // random_in_unit_sphere (cuda_utils/curand_state.cuh:93-109) tests the vector against the unit ball
+          // around (0.5, 0.5, 0.5) and returns it UNcentred; in (0,1]^3 the test cannot fail (<= 0.75)
+          for (;;) {
+            const float cx = rx - 0.5f, cy = ry - 0.5f, cz = rz - 0.5f;
+            if (dot3(cx, cy, cz, cx, cy, cz) <= 1.0f) break;
+            rx = uniform(); ry = uniform(); rz = uniform();
+          }
+          bdx = hnx + rx; bdy = hny + ry; bdz = hnz + rz;
+        } else { // MetallicMaterial::bounce, core/material.cuh:126-132, :151-158
+          const float s2 = 2.0f * dot3(dx, dy, dz, hnx, hny, hnz);
+          bdx = dx - s2 * hnx; bdy = dy - s2 * hny; bdz = dz - s2 * hnz;
+        }
         if (depth + 1 > A.max_depth) { // what the recursive call returns beyond the limit, src/main.cu:51-53
           inr = 0.01f; ing = 0.01f; inb = 0.01f;
           levels = depth + 1;
           alive = false;
-        } else { // MetallicMaterial::bounce, core/material.cuh:126-132, :151-158
-          const float s2 = 2.0f * dot3(dx, dy, dz, hnx, hny, hnz);
+        } else {
           ox = hpx; oy = hpy; oz = hpz;
-          dx = dx - s2 * hnx; dy = dy - s2 * hny; dz = dz - s2 * hnz;
+          dx = bdx; dy = bdy; dz = bdz;
         }
       }
     }

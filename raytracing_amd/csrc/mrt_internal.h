@@ -71,6 +71,10 @@ struct RenderArgs {
   const float *utab, *vtab;
   int32_t wide;
   float cone_ext;                   // cull kernel: max |ray - tile centre ray| over a padded tile (launcher)
+  // diffuse bounces (mrt_bounce.hip, mrt_rng.hip): xorshift words of pixel i at rng[k * rng_stride + i], k = 0..4,
+  // and the Weyl counter every stream starts with; null when no stream is needed
+  const uint32_t *rng;
+  uint32_t rng_stride, rng_d;
 };
 
 hipError_t launch_render_cull(const RenderArgs &args, hipStream_t stream);
@@ -89,8 +93,16 @@ struct SmallHost {
 hipError_t launch_render_small(const RenderArgs &args, const SmallHost &host, hipStream_t stream);
 hipError_t launch_uv_table(float *utab, int nu, int W, float *vtab, int nv, int H, hipStream_t stream);
 
-// mirror chains, max_depth 1..8, all-metallic scenes (mrt_bounce.hip)
+// bounce chains, max_depth 1..8 (mrt_bounce.hip); a scene with a diffuse object needs args.rng
 hipError_t launch_render_bounce(const RenderArgs &args, hipStream_t stream);
+
+// per-pixel XORWOW streams (mrt_rng.hip): jump matrices A^(2^(67+b)), b < RNG_JUMP_MATRICES, 800 words each
+enum { RNG_JUMP_MATRICES = 32 };
+const uint32_t *rng_jump_tables();
+void rng_seed_state(uint64_t seed, uint32_t v[5], uint32_t *d);
+void rng_host_state(uint64_t seed, uint32_t subsequence, uint32_t out6[6]);
+hipError_t launch_rng_init(const uint32_t *jump_dev, uint32_t *states, uint32_t n, uint32_t stride, uint64_t seed,
+                           hipStream_t stream);
 
 // launchers (mrt_kernels.hip)
 hipError_t launch_render(const RenderArgs &args, hipStream_t stream);

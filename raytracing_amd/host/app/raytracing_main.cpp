@@ -1,6 +1,9 @@
 // app/raytracing_main.cpp -- the reference's CLI, `raytracing <image-filename>`
 // (src/main.cu:159-260), on the MI355X back end: build the hard-coded scene, render on one
-// GPU through the C-ABI, flip, write a Radiance .hdr.  Optional: width height spp.
+// GPU through the C-ABI, flip, write a Radiance .hdr.  With the file name alone it renders what the
+// reference binary renders: 2048x1024 (src/main.cu:165), 121 samples per pixel (pipeline/multisample_mesh.cuh),
+// bounce chains up to config::MAX_RECURSION_DEPTH = 8 (src/main.cu:26), random streams seeded with 1984
+// (cuda_utils/curand_state.cuh:22).  Optional: width height, samples (1 | 121), depth (0..8).
 #include <cstdio>
 #include <cstdlib>
 
@@ -10,17 +13,18 @@
 
 static void print_help_and_exit(const char *name)
 {
-  std::printf("usage %s <image-filename> [width height [spp]]\n", name);
+  std::printf("usage %s <image-filename> [width height [spp [max-depth]]]\n", name);
   std::exit(EXIT_FAILURE);
 }
 
 int main(int argc, char **argv)
 {
-  if (argc != 2 && argc != 4 && argc != 5) print_help_and_exit(*argv);
+  if (argc != 2 && argc != 4 && argc != 5 && argc != 6) print_help_and_exit(*argv);
   std::size_t W = 2048, H = 1024; // src/main.cu:165
-  int spp = 1;
+  int spp = 121, max_depth = 8;
   if (argc >= 4) { W = std::strtoul(argv[2], nullptr, 10); H = std::strtoul(argv[3], nullptr, 10); }
-  if (argc == 5) spp = std::atoi(argv[4]);
+  if (argc >= 5) spp = std::atoi(argv[4]);
+  if (argc == 6) max_depth = std::atoi(argv[5]);
   if (W == 0 || H == 0) print_help_and_exit(*argv);
 
   rt::ImageBuffer img(W, H);
@@ -29,8 +33,8 @@ int main(int argc, char **argv)
 
   rt::Renderer renderer(0);
   renderer.upload(rt::make_view(scene.objects), rt::make_view(scene.lights));
-  mrt_stats st = renderer.render(viewport, img, spp, 0);
-  std::printf("rendered %zux%zu spp %d: %llu primary + %llu shadow rays, kernel %.3f ms\n", W, H, spp,
+  mrt_stats st = renderer.render(viewport, img, spp, max_depth);
+  std::printf("rendered %zux%zu spp %d depth %d: %llu primary + %llu shadow rays, kernel %.3f ms\n", W, H, spp, max_depth,
               (unsigned long long)st.primary_rays, (unsigned long long)st.shadow_rays, st.kernel_ms);
 
   img.flip_vertical();

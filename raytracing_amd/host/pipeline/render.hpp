@@ -120,6 +120,10 @@ public:
     return st;
   }
 
+  // seed of the per-pixel random streams of diffuse bounces; the reference hard-codes 1984
+  // (cuda_utils/curand_state.cuh:22), which is also the back end's default
+  void seed_random_streams(int seed) { checkRtErrors(mrt_ctx_set_option(ctx_, MRT_OPT_RNG_SEED, seed)); }
+
   mrt_ctx *ctx() { return ctx_; }
 
 private:

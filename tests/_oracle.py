@@ -50,6 +50,14 @@ def _load():
     lib.orc_triangle16_hit.argtypes = [_f3, _f3, _f3, C.c_float, C.c_float, _f3, _f3, _f3]
     lib.orc_render.argtypes = [C.c_void_p, _f3, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(OrcStats)]
+    lib.orc_scene_set_rng_seed.argtypes = [C.c_void_p, C.c_uint64]
+    lib.orc_scene_set_rng_seed.restype = None
+    lib.orc_xorwow_init.argtypes = [C.c_uint64, C.c_uint64, C.c_void_p]
+    lib.orc_xorwow_init.restype = None
+    lib.orc_xorwow_draw.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+    lib.orc_xorwow_draw.restype = None
+    lib.orc_xorwow_pow2_matrix.argtypes = [C.c_int, C.c_void_p]
+    lib.orc_xorwow_pow2_matrix.restype = None
     return lib
 
 
@@ -128,6 +136,9 @@ class Scene:
     def add_point_light(self, p, rgb):
         return lib().orc_add_point_light(self._h, _v(p), _v(rgb))
 
+    def set_rng_seed(self, seed):
+        lib().orc_scene_set_rng_seed(self._h, int(seed))
+
     @property
     def num_objects(self):
         return lib().orc_scene_num_objects(self._h)
@@ -149,6 +160,28 @@ class Scene:
         if rc != 0:
             raise RuntimeError(f"orc_render failed: {rc}")
         return {"rgb": rgb, "id": ids, "t": t, "stats": st.as_dict()}
+
+
+def xorwow_init(seed, subsequence):
+    """curand_init(seed, subsequence, 0): uint32[6] = v[0..4], d."""
+    st = np.zeros(6, dtype=np.uint32)
+    lib().orc_xorwow_init(int(seed), int(subsequence), st.ctypes.data)
+    return st
+
+
+def xorwow_draw(state6, n):
+    """n draws: (state after, raw uint32[n], curand_uniform float32[n])."""
+    st = np.array(state6, dtype=np.uint32)
+    raw = np.zeros(n, dtype=np.uint32)
+    uni = np.zeros(n, dtype=np.float32)
+    lib().orc_xorwow_draw(st.ctypes.data, int(n), raw.ctypes.data, uni.ctypes.data)
+    return st, raw, uni
+
+
+def xorwow_pow2_matrix(log2):
+    m = np.zeros((160, 5), dtype=np.uint32)
+    lib().orc_xorwow_pow2_matrix(int(log2), m.ctypes.data)
+    return m
 
 
 def viewport(look_from, look_at, up, vfov_deg, aspect):
