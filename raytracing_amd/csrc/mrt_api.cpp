@@ -51,6 +51,7 @@ struct mrt_ctx {
   uint32_t *rng_mem = nullptr;
   uint32_t rng_n = 0;
   uint64_t rng_seed = 1984, rng_built_seed = 0; // cuda_utils/curand_state.cuh:22
+
 };
 
 static thread_local std::string g_create_err;
@@ -145,7 +146,14 @@ static hipError_t launch_by_mode(mrt_ctx *ctx, mrt::RenderArgs &A, hipStream_t s
       mrt::rng_seed_state(ctx->rng_seed, v, &A.rng_d);
       A.rng = ctx->rng_mem; A.rng_stride = ctx->rng_n;
     }
-    return mrt::launch_render_bounce(A, st);
+    const bool small = (long)A.sc.ns + A.sc.nt <= 64;
+    mrt::SmallHost hs;
+    if (small) {
+      hs.ns = (int)ctx->small_sph_obj.size(); hs.nt = (int)ctx->small_tri_obj.size();
+      hs.sph = ctx->small_sph.data(); hs.sph_obj = ctx->small_sph_obj.data();
+      hs.tri16 = ctx->small_tri16.data(); hs.tri_obj = ctx->small_tri_obj.data();
+    }
+    return mrt::launch_render_bounce(A, small ? &hs : nullptr, st);
   }
   int mode = ctx->cull;
   const bool small = (long)A.sc.ns + A.sc.nt <= 64;

@@ -17,12 +17,17 @@
 
 #include "mrt_internal.h"
 #include "mrt_device.h"
+#include "mrt_cull_common.h"
+
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
 
 namespace mrt {
 
 constexpr int MAX_LEVELS = 9; // depths 0..8
 
-__global__ __launch_bounds__(256) void render_bounce_kernel(RenderArgs A)
+__global__ __launch_bounds__(256) void render_bounce_coupled_kernel(RenderArgs A)
 {
   const DevScene &sc = A.sc;
   const DevCamera &cam = A.cam;
@@ -283,12 +288,516 @@ __global__ __launch_bounds__(256) void render_bounce_kernel(RenderArgs A)
   }
 }
 
-hipError_t launch_render_bounce(const RenderArgs &A, hipStream_t stream)
+
+// ---- the default kernel: every lane runs its own (sample, level) state machine --------------------------------
+// In the kernel above a wave finishes a sample only when its longest chain has ended: with diffuse bounces some
+// lane nearly always has a long one, and the wave pays max-over-lanes levels for every one of 121 samples.  But
+// every step of every chain is the same work -- closest hit over all primitives, shadow rays over all primitives,
+// one bounce -- whatever sample and level a lane is at.  So here a lane that ends a chain folds it, adds it to its
+// pixel and starts its next sample at once; the wave runs until the lane with the most steps IN TOTAL is done
+// (sum over samples instead of a maximum per sample).  Per lane the order of samples, levels and random draws is
+// the reference's, so results do not change.  The level stack is indexed per lane now: it lives in registers and
+// is written and folded through unrolled selects (9 levels x 6 floats).
+// Tiles whose padded cone of primary rays (all 121 sample positions included) misses every primitive bound take a
+// second shortcut: every chain is the sky colour of its primary ray; nothing is tested and nothing is drawn.
+__device__ __forceinline__ const RenderArgs &args_of(const RenderArgs &a) { return a; }
+__device__ __forceinline__ const RenderArgs &args_of(const SmallArgs &s) { return s.A; }
+__device__ __forceinline__ float prm_of(const RenderArgs &, int, int) { return 0.0f; }
+__device__ __forceinline__ float prm_of(const SmallArgs &s, int f, int lane) { return s.prm[f][lane]; }
+
+template <bool MULTI, bool SMALL, class Args>
+__device__ __forceinline__ void render_bounce_body(const Args &S)
 {
-  if (A.max_depth < 1 || A.max_depth > MAX_LEVELS - 1) return hipErrorInvalidValue;
-  const int tiles_x = (A.W + 7) / 8, tiles_y = (A.local_rows + 7) / 8;
+  const RenderArgs &A = args_of(S);
+  const DevScene &sc = A.sc;
+  const DevCamera &cam = A.cam;
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int tx = lane & 7, ty = lane >> 3;
+  const int ns = sc.ns, nt = sc.nt;
+
+  const int tile_x = blockIdx.x * 4 + wave;
+  const int tile_y = blockIdx.y;
+  if (tile_x * 8 >= A.W) return; // waves are independent: no barrier below
+  const int col = tile_x * 8 + tx;
+  const int lrow = tile_y * 8 + ty;
+  const int lrow0 = tile_y * 8;
+  const int strip = lrow0 / A.strip_rows;
+  const int grow0 = (strip * A.nranks + A.rank) * A.strip_rows + (lrow0 - strip * A.strip_rows);
+  const int grow = grow0 + ty;
+  const bool valid = (lrow < A.local_rows) && (grow < A.H) && (col < A.W);
+
+  const int nsamp = MULTI ? A.spp : 1;
+  const float DIVW = 13.0f, DIVH = 13.0f;
+  const float u0 = float(col) / float(A.W); // src/main.cu:136
+  const float v0 = float(grow) / float(A.H); // src/main.cu:137
+  float ox = cam.ox, oy = cam.oy, oz = cam.oz, dx = 0.0f, dy = 0.0f, dz = 0.0f; // current ray of the lane's chain
+  // sample offsets of the 11 x 11 mesh (pipeline/multisample_mesh.cuh:23-30): four IEEE divisions per sample if
+  // computed on the spot; instead every wave tabulates its 22 values once (LDS, one slice per wave) and lanes
+  // look theirs up -- lanes sit at different samples, and a table read does not care which lanes are active
+  __shared__ float offtab[4][32];
+  if (MULTI) {
+    if (lane < 11) offtab[wave][lane] = (-1.0f + 2.0f * float(lane + 1) / DIVW) / float(A.W);
+    else if (lane >= 16 && lane < 27) offtab[wave][lane] = (-1.0f + 2.0f * float(lane - 16 + 1) / DIVH) / float(A.H);
+    __builtin_amdgcn_wave_barrier(); // the table is written and read by this wave only
+  }
+  auto primary_ray = [&](int sidx) { // pipeline/viewport.cuh:30-34
+    float su = u0, sv = v0;
+    if (MULTI) {
+      const int r = sidx / 11, c = sidx - r * 11;
+      su = u0 + offtab[wave][c]; sv = v0 + offtab[wave][16 + r];
+    }
+    ox = cam.ox; oy = cam.oy; oz = cam.oz;
+    dx = ((cam.ux + su * cam.hx) + sv * cam.vx) - cam.ox;
+    dy = ((cam.uy + su * cam.hy) + sv * cam.vy) - cam.oy;
+    dz = ((cam.uz + su * cam.hz) + sv * cam.vz) - cam.oz;
+  };
+  auto sky = [&](float &r, float &g, float &b) { // background, src/main.cu:101-104
+    float nx = dx, ny = dy, nz = dz;
+    normalize3(nx, ny, nz);
+    const float y = 0.5f * (ny + 1.0f);
+    const float w0 = 1.0f - y;
+    r = w0 * 1.0f + y * 0.5f; g = w0 * 1.0f + y * 0.7f; b = w0 * 1.0f + y * 1.0f;
+  };
+
+  float accr = 0.0f, accg = 0.0f, accb = 0.0f;
+  int out_id = -1;
+  float out_t = MRT_INF;
+  unsigned int n_shadow = 0, n_hit = 0, n_occl = 0;
+  unsigned int n_steps = 0, n_iter = 0; // wave-uniform diagnostics: lane steps and wave iterations of the chain loop
+
+  // ---- can any primary ray of the tile hit anything?  Cone around the tile's rays, padded by one pixel on
+  //      every side (covers the sub-pixel sample offsets), against every primitive bound; as in mrt_cull.hip ----
+  bool tile_has_candidates;
+  unsigned long long primary_mask = ~0ull; // SMALL: primitives (bit = lane) a primary ray of the tile may hit
+  {
+    float cax, cay, caz, cosT, sinT;
+    const float rw = fast_rcp(float(A.W)), rh = fast_rcp(float(A.H));
+    const float um = (float(tile_x * 8) + 3.5f) * rw, vm = (float(grow0) + 3.5f) * rh;
+    cax = ((cam.ux + um * cam.hx) + vm * cam.vx) - cam.ox;
+    cay = ((cam.uy + um * cam.hy) + vm * cam.vy) - cam.oy;
+    caz = ((cam.uz + um * cam.hz) + vm * cam.vz) - cam.oz;
+    const float inv = fast_rsq(dot3(cax, cay, caz, cax, cay, caz));
+    cax *= inv; cay *= inv; caz *= inv;
+    sinT = A.cone_ext * inv * (1.0f + 1e-4f) + 1e-6f;
+    cosT = fast_sqrt(fmaxf(1.0f - sinT * sinT, 0.0f)) * (1.0f - 1e-5f) - 1e-6f;
+    if (!(sinT < 0.99f) || !(cosT > 0.0f)) { cosT = -1.0f; sinT = 0.0f; } // cannot cull: every ball passes
+    bool pass = false;
+    if (SMALL) { // lane = primitive (spheres first): cone test / screen-space edge functions, as in mrt_small.hip
+      if (lane < ns) {
+        pass = ball_may_touch_cone(prm_of(S, 0, lane), prm_of(S, 1, lane), prm_of(S, 2, lane), prm_of(S, 3, lane), cax,
+                                   cay, caz, cosT, sinT);
+      } else if (lane < ns + nt) {
+        bool cull = false;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const float f = __builtin_fmaf(um, prm_of(S, 3 * i + 1, lane), __builtin_fmaf(vm, prm_of(S, 3 * i + 2, lane), prm_of(S, 3 * i, lane)));
+          cull |= (f < 0.0f); // NaN compares false: never culls
+        }
+        pass = !cull;
+      }
+      primary_mask = __ballot(pass);
+    } else {
+      for (int base = 0; base < ns && !__any(pass); base += 64) {
+        const int i = base + lane;
+        if (i < ns) {
+          const float r = sc.sph_r[i];
+          const float wx = sc.sph_cx[i] - cam.ox, wy = sc.sph_cy[i] - cam.oy, wz = sc.sph_cz[i] - cam.oz;
+          pass = ball_may_touch_cone(wx, wy, wz, sphere_cull_radius(r * r, dot3(wx, wy, wz, wx, wy, wz)), cax, cay, caz,
+                                     cosT, sinT);
+        }
+      }
+      for (int base = 0; base < nt && !__any(pass); base += 64) {
+        const int i = base + lane;
+        if (i < nt)
+          pass = ball_may_touch_cone(sc.tri_bx[i] - cam.ox, sc.tri_by[i] - cam.oy, sc.tri_bz[i] - cam.oz,
+                                     sc.tri_br[i] * CULL_REL + CULL_ABS, cax, cay, caz, cosT, sinT);
+      }
+    }
+    tile_has_candidates = __any(pass);
+  }
+
+  // SMALL: lane j keeps the bound of primitive j (spheres first) for the shadow-ray culling below
+  float pbx = 0.0f, pby = 0.0f, pbz = 0.0f, pbr = 0.0f; // sphere: centre, radius; triangle: bounding ball
+  const bool own_s = SMALL && lane < ns, own_t = SMALL && lane >= ns && lane < ns + nt;
+  if (tile_has_candidates) {
+    if (own_s) { pbx = sc.sph_cx[lane]; pby = sc.sph_cy[lane]; pbz = sc.sph_cz[lane]; pbr = sc.sph_r[lane]; }
+    else if (own_t) { const int k = lane - ns; pbx = sc.tri_bx[k]; pby = sc.tri_by[k]; pbz = sc.tri_bz[k]; pbr = sc.tri_br[k]; }
+  }
+  // primitive data comes through wave-uniform scalar loads (keeping a small scene in registers and broadcasting
+  // it with readlane was measured slower: 16 readlanes per triangle against one s_load_dwordx16)
+  auto sphere_of = [&](int i, float &cx, float &cy, float &cz, float &r, int &obj) {
+    cx = sc.sph_cx[i]; cy = sc.sph_cy[i]; cz = sc.sph_cz[i]; r = sc.sph_r[i];
+    obj = sc.sph_obj[i];
+  };
+  auto triangle_of = [&](int i, float (&q)[16], int &obj) {
+    const float *m = sc.tri_rec + 16 * size_t(i);
+#pragma unroll
+    for (int k = 0; k < 16; ++k) q[k] = m[k];
+    obj = sc.tri_obj[i];
+  };
+
+  if (!tile_has_candidates) {
+    for (int sidx = 0; sidx < nsamp; ++sidx) {
+      primary_ray(sidx);
+      float r, g, b;
+      sky(r, g, b);
+      accr += r; accg += g; accb += b; // src/main.cu:151
+    }
+  } else {
+    // src/main.cu:133-135: a private copy of the pixel's state; never written back
+    const bool use_rng = A.rng != nullptr;
+    uint32_t g0 = 0, g1 = 0, g2 = 0, g3 = 0, g4 = 0, gd = A.rng_d;
+    if (use_rng && valid) {
+      const size_t pi = size_t(grow) * A.W + col, rs = A.rng_stride;
+      g0 = A.rng[pi]; g1 = A.rng[rs + pi]; g2 = A.rng[2 * rs + pi]; g3 = A.rng[3 * rs + pi]; g4 = A.rng[4 * rs + pi];
+    }
+    auto uniform = [&]() -> float { // curand_uniform: xorwow draw, then x * 2^-32 + 2^-33
+      const uint32_t tt = g0 ^ (g0 >> 2);
+      g0 = g1; g1 = g2; g2 = g3; g3 = g4;
+      g4 = (g4 ^ (g4 << 4)) ^ (tt ^ (tt << 1));
+      gd += 362437u;
+      return float(g4 + gd) * 2.3283064e-10f + (2.3283064e-10f / 2.0f);
+    };
+
+    float stC[MAX_LEVELS][3], stL[MAX_LEVELS][3]; // per level: object colour, direct light (registers: static indices only)
+    unsigned int stH = 0;                         // bit k: a light contributed at level k
+    int sidx = 0, depth = 0;
+    bool work = valid; // lanes outside the frame have nothing to do
+    if (work) primary_ray(0);
+
+    // Two kinds of iteration.  Primary: every lane that is at level 0 takes its step; with SMALL only the tile's
+    // candidate primitives are tested (the primary rays of all samples lie in the tile's padded cone).  Lanes
+    // further down a chain wait.  Deep: when no lane is at level 0, or A.s_cap lanes are waiting (8: measured
+    // best on the reference's frame, 7.8 ms against 9.2 with "only when no lane is at level 0" and 8.2 with 16),
+    // the waiting lanes take one step against every primitive.  Waiting fills the expensive iterations: most
+    // chains end at level 0 or 1.
+    const int deep_threshold = A.s_cap > 0 ? A.s_cap : 64;
+    while (true) {
+      const unsigned long long wmask = __ballot(work);
+      if (!wmask) break;
+      const unsigned long long m0 = __ballot(work && depth == 0);
+      const bool primary_iter = m0 != 0 && __popcll(wmask & ~m0) < deep_threshold;
+      const bool act = work && ((depth == 0) == primary_iter);
+      n_steps += __popcll(__ballot(act)); n_iter++;
+      // ---- closest hit: src/main.cu:60-77, interval [0.01, inf] ----
+      const float aa = dot3(dx, dy, dz, dx, dy, dz);
+      float best_t = MRT_INF;
+      int best_obj = 0x7fffffff, best_prim = -1;
+      auto hit_sphere = [&](int i) { // core/sphere.cuh:32-73
+        float cx, cy, cz, r;
+        int obj;
+        sphere_of(i, cx, cy, cz, r, obj);
+        const float ocx = ox - cx, ocy = oy - cy, ocz = oz - cz;
+        const float b = dot3(ocx, ocy, ocz, dx, dy, dz);
+        const float c = dot3(ocx, ocy, ocz, ocx, ocy, ocz) - r * r;
+        const float disc = b * b - aa * c;
+        if (disc >= 0.0f) {
+          float t;
+          if (sphere_roots(aa, b, disc, 0.01f, MRT_INF, t)) {
+            if (t < best_t || (t == best_t && t < MRT_INF && obj < best_obj)) { best_t = t; best_obj = obj; best_prim = i; }
+          }
+        }
+      };
+      auto hit_triangle = [&](int i) { // core/triangle.cuh:77-103
+        float q[16];
+        int obj;
+        triangle_of(i, q, obj);
+        const float pnx = q[0], pny = q[1], pnz = q[2], kp = q[3];
+        const float rdn = dot3(dx, dy, dz, pnx, pny, pnz);
+        const float t = (kp - dot3(ox, oy, oz, pnx, pny, pnz)) / rdn;
+        // the edge tests only matter in lanes whose t is in range and could still win: none in the wave, skip
+        if (!__any(act & (rdn != 0.0f) & (0.01f <= t) & (t <= best_t))) return;
+        const float px = ox + t * dx, py = oy + t * dy, pz = oz + t * dz;
+        const float e0 = dot3(q[4], q[5], q[6], px, py, pz) - q[7];
+        const float e1 = dot3(q[8], q[9], q[10], px, py, pz) - q[11];
+        const float e2 = dot3(q[12], q[13], q[14], px, py, pz) - q[15];
+        const bool hit = (rdn != 0.0f) & (e0 > -1e-6f) & (e1 > -1e-6f) & (e2 > -1e-6f) & (0.01f <= t) & (t <= MRT_INF);
+        if (hit) {
+          if (t < best_t || (t == best_t && t < MRT_INF && obj < best_obj)) { best_t = t; best_obj = obj; best_prim = ns + i; }
+        }
+      };
+      if (SMALL && primary_iter) {
+        unsigned long long mask = primary_mask;
+        while (mask) {
+          const int j = __builtin_ctzll(mask);
+          mask &= mask - 1;
+          if (j < ns) hit_sphere(j); else hit_triangle(j - ns);
+        }
+      } else {
+        for (int i = 0; i < ns; ++i) hit_sphere(i);
+        for (int i = 0; i < nt; ++i) hit_triangle(i);
+      }
+      const bool have_hit = act && best_prim >= 0;
+      if (act && depth == 0) { // the ID / t buffers describe the primary hit (of the last sample)
+        out_id = have_hit ? best_obj : -1;
+        out_t = best_t;
+        if (have_hit) n_hit++;
+      }
+      bool finish = false;
+      int levels = 0;
+      float inr = 0.0f, ing = 0.0f, inb = 0.0f; // what the end of the chain returns
+      if (act && !have_hit) {                   // the chain ends in the sky
+        sky(inr, ing, inb);
+        levels = depth;
+        finish = true;
+      }
+
+      // ---- hit record (core/sphere.cuh:45-47, core/triangle.cuh:96-97) ----
+      float hpx = 0.0f, hpy = 0.0f, hpz = 0.0f, hnx = 0.0f, hny = 0.0f, hnz = 0.0f;
+      if (have_hit) {
+        hpx = ox + best_t * dx; hpy = oy + best_t * dy; hpz = oz + best_t * dz;
+        float g0, g1, g2; // sphere centre / triangle plane normal of the lane's own hit
+        if (best_prim < ns) {
+          g0 = sc.sph_cx[best_prim]; g1 = sc.sph_cy[best_prim]; g2 = sc.sph_cz[best_prim];
+        } else {
+          const float *q = sc.tri_rec + 16 * size_t(best_prim - ns);
+          g0 = q[0]; g1 = q[1]; g2 = q[2];
+        }
+        if (best_prim < ns) {
+          float nx = hpx - g0, ny = hpy - g1, nz = hpz - g2;
+          normalize3(nx, ny, nz);
+          hnx = nx; hny = ny; hnz = nz;
+        } else {
+          const float pnx = g0, pny = g1, pnz = g2;
+          const bool front = dot3(dx, dy, dz, pnx, pny, pnz) < 0;
+          hnx = front ? pnx : -pnx; hny = front ? pny : -pny; hnz = front ? pnz : -pnz;
+        }
+      }
+
+      // ---- shadow rays + direct light at this level: core/light.cuh:135-178 ----
+      float lr = 0.0f, lg = 0.0f, lb = 0.0f;
+      bool have_light = false;
+      if (__any(have_hit)) {
+        const bool diffuse_obj = have_hit && sc.mat_kind[best_obj] == 0;
+        // SMALL: ball around the hit points of this iteration (centre = the first one); with a light it spans the
+        // bundle of shadow rays that each primitive's bound is tested against (mrt_cull_common.h), one primitive
+        // per lane.  Valid for any set of hit points; tight in primary iterations, loose in deep ones.
+        Bundle B;
+        if (SMALL) {
+          const int first = __builtin_ctzll(__ballot(have_hit));
+          B.mx = bcast(hpx, first); B.my = bcast(hpy, first); B.mz = bcast(hpz, first);
+          const float ex = hpx - B.mx, ey = hpy - B.my, ez = hpz - B.mz;
+          B.rho = fast_sqrt(wave_max(have_hit ? dot3(ex, ey, ez, ex, ey, ez) : 0.0f)) * CULL_REL + CULL_ABS;
+        }
+        for (int li = 0; li < sc.nl; ++li) {
+          const int lkind = sc.light_kind[li];
+          const float lvx = sc.light_vec[3 * li], lvy = sc.light_vec[3 * li + 1], lvz = sc.light_vec[3 * li + 2];
+          float sdx, sdy, sdz, tl, lnx, lny, lnz; // ray_from: core/light.cuh:73-81 / :47-53
+          if (lkind == 0) {
+            sdx = -lvx; sdy = -lvy; sdz = -lvz; tl = MRT_INF;
+            lnx = lvx; lny = lvy; lnz = lvz;
+          } else {
+            sdx = lvx - hpx; sdy = lvy - hpy; sdz = lvz - hpz; tl = 1.0f;
+            lnx = hpx - lvx; lny = hpy - lvy; lnz = hpz - lvz;
+            normalize3(lnx, lny, lnz);
+          }
+          const float sa = dot3(sdx, sdy, sdz, sdx, sdy, sdz);
+          const bool need = have_hit && !(dot3(sdx, sdy, sdz, hnx, hny, hnz) < 0); // core/light.cuh:148
+          bool open = need;
+          // any-hit over every object, interval [1e-3, t_light] (core/light.cuh:28-33, :153-158)
+          auto shadow_sphere = [&](int i) {
+            float cx, cy, cz, r;
+            int obj_unused;
+            sphere_of(i, cx, cy, cz, r, obj_unused);
+            const float ocx = hpx - cx, ocy = hpy - cy, ocz = hpz - cz;
+            const float b = dot3(ocx, ocy, ocz, sdx, sdy, sdz);
+            const float c = dot3(ocx, ocy, ocz, ocx, ocy, ocz) - r * r;
+            const float disc = b * b - sa * c;
+            if (open && disc >= 0.0f) {
+              float t;
+              if (sphere_roots(sa, b, disc, 1e-3f, tl, t)) open = false;
+            }
+          };
+          auto shadow_triangle = [&](int i) {
+            float q[16];
+            int obj_unused;
+            triangle_of(i, q, obj_unused);
+            const float pnx = q[0], pny = q[1], pnz = q[2], kp = q[3];
+            const float rdn = dot3(sdx, sdy, sdz, pnx, pny, pnz);
+            const float t = (kp - dot3(hpx, hpy, hpz, pnx, pny, pnz)) / rdn;
+            if (!__any(open & (rdn != 0.0f) & (1e-3f <= t) & (t <= tl))) return;
+            const float px = hpx + t * sdx, py = hpy + t * sdy, pz = hpz + t * sdz;
+            const float e0 = dot3(q[4], q[5], q[6], px, py, pz) - q[7];
+            const float e1 = dot3(q[8], q[9], q[10], px, py, pz) - q[11];
+            const float e2 = dot3(q[12], q[13], q[14], px, py, pz) - q[15];
+            const bool h = (rdn != 0.0f) & (e0 > -1e-6f) & (e1 > -1e-6f) & (e2 > -1e-6f) & (1e-3f <= t) & (t <= tl);
+            if (open && h) open = false;
+          };
+          if (SMALL) {
+            unsigned long long mask = 0;
+            if (__any(open)) {
+              B.point = lkind != 0;
+              if (lkind == 0) { B.Dx = -lvx; B.Dy = -lvy; B.Dz = -lvz; }
+              else { B.Dx = lvx - B.mx; B.Dy = lvy - B.my; B.Dz = lvz - B.mz; }
+              B.DD = dot3(B.Dx, B.Dy, B.Dz, B.Dx, B.Dy, B.Dz);
+              bool pass = false;
+              if (own_s) {
+                const float wx = pbx - B.mx, wy = pby - B.my, wz = pbz - B.mz;
+                const float Lm = fast_sqrt(dot3(wx, wy, wz, wx, wy, wz)) * CULL_REL + B.rho; // >= |hit point - centre|
+                pass = bundle_may_touch(B, pbx, pby, pbz, sphere_cull_radius(pbr * pbr, Lm * Lm));
+              } else if (own_t) {
+                pass = bundle_may_touch(B, pbx, pby, pbz, pbr);
+              }
+              mask = __ballot(pass);
+            }
+            while (mask && __any(open)) {
+              const int j = __builtin_ctzll(mask);
+              mask &= mask - 1;
+              if (j < ns) shadow_sphere(j); else shadow_triangle(j - ns);
+            }
+          } else {
+            for (int i = 0; i < ns && __any(open); ++i) shadow_sphere(i);
+            for (int i = 0; i < nt && __any(open); ++i) shadow_triangle(i);
+          }
+          if (need) { n_shadow++; if (!open) n_occl++; }
+          if (open) {
+            // light_bounce with the LIGHT's normal, as the reference passes it (core/light.cuh:164-168);
+            // the viewing ray is the current ray of the chain
+            const float lcr = sc.light_rgb[3 * li], lcg = sc.light_rgb[3 * li + 1], lcb = sc.light_rgb[3 * li + 2];
+            const float dn = dot3(sdx, sdy, sdz, lnx, lny, lnz);
+            float cr, cg, cb;
+            if (diffuse_obj) { // DiffuseMaterial::light_bounce, core/material.cuh:63-75
+              const float scale = -dn;
+              if (scale > 0.0f) { cr = scale * lcr; cg = scale * lcg; cb = scale * lcb; }
+              else { cr = 0.0f; cg = 0.0f; cb = 0.0f; }
+            } else {           // MetallicMaterial::light_bounce, core/material.cuh:134-158
+              const float s2 = 2.0f * dn;
+              const float rx = sdx - s2 * lnx, ry = sdy - s2 * lny, rz = sdz - s2 * lnz;
+              if (dot3(rx, ry, rz, dx, dy, dz) < -0.99f) { cr = lcr; cg = lcg; cb = lcb; }
+              else { cr = 0.001f; cg = 0.001f; cb = 0.001f; }
+            }
+            if (have_light) { lr += cr; lg += cg; lb += cb; }
+            else { lr = cr; lg = cg; lb = cb; have_light = true; }
+          }
+        }
+      }
+
+      // ---- push the level; continue with the bounced ray or end the chain ----
+      if (have_hit) {
+        const float *m = sc.mat_rgb + 3 * best_obj;
+        const float m0 = m[0], m1 = m[1], m2 = m[2];
+#pragma unroll
+        for (int k = 0; k < MAX_LEVELS; ++k)
+          if (k == depth) {
+            stC[k][0] = m0; stC[k][1] = m1; stC[k][2] = m2;
+            stL[k][0] = lr; stL[k][1] = lg; stL[k][2] = lb;
+          }
+        stH = have_light ? (stH | (1u << depth)) : (stH & ~(1u << depth));
+        // the bounce (src/main.cu:80-83) happens at every level, the last one included: a diffuse surface
+        // advances the pixel's stream even when its bounce ray is never followed
+        float bdx, bdy, bdz;
+        if (use_rng && sc.mat_kind[best_obj] == 0) { // DiffuseMaterial::bounce, core/material.cuh:52-61
+          float rx = uniform(), ry = uniform(), rz = uniform();
+          // random_in_unit_sphere (cuda_utils/curand_state.cuh:93-109) tests the vector against the unit ball
+          // around (0.5, 0.5, 0.5) and returns it UNcentred; in (0,1]^3 the test cannot fail (<= 0.75)
+          for (;;) {
+            const float cx = rx - 0.5f, cy = ry - 0.5f, cz = rz - 0.5f;
+            if (dot3(cx, cy, cz, cx, cy, cz) <= 1.0f) break;
+            rx = uniform(); ry = uniform(); rz = uniform();
+          }
+          bdx = hnx + rx; bdy = hny + ry; bdz = hnz + rz;
+        } else { // MetallicMaterial::bounce, core/material.cuh:126-132, :151-158
+          const float s2 = 2.0f * dot3(dx, dy, dz, hnx, hny, hnz);
+          bdx = dx - s2 * hnx; bdy = dy - s2 * hny; bdz = dz - s2 * hnz;
+        }
+        if (depth + 1 > A.max_depth) { // what the recursive call returns beyond the limit, src/main.cu:51-53
+          inr = 0.01f; ing = 0.01f; inb = 0.01f;
+          levels = depth + 1;
+          finish = true;
+        } else {
+          ox = hpx; oy = hpy; oz = hpz;
+          dx = bdx; dy = bdy; dz = bdz;
+          depth++;
+        }
+      }
+
+      // ---- a chain ended: fold it (src/main.cu:91-98, innermost level first), add it to the pixel, next sample ----
+      if (__any(finish)) {
+        float cr = inr, cg = ing, cb = inb;
+#pragma unroll
+        for (int k = MAX_LEVELS - 1; k >= 0; --k) {
+          if (!__any(finish && k < levels)) continue; // most chains are short: skip the levels no lane has
+          if (k < levels) {
+            const float mr = stC[k][0], mg = stC[k][1], mb = stC[k][2];
+            if (stH & (1u << k)) { cr = cr * mr + stL[k][0] * mr; cg = cg * mg + stL[k][1] * mg; cb = cb * mb + stL[k][2] * mb; }
+            else { cr = cr * mr; cg = cg * mg; cb = cb * mb; }
+          }
+        }
+        if (finish) {
+          accr += cr; accg += cg; accb += cb; // src/main.cu:151
+          sidx++;
+          depth = 0;
+          work = sidx < nsamp;
+          if (work) primary_ray(sidx);
+        }
+      }
+    }
+  }
+
+  if (valid) { // src/main.cu:155
+    const float fn = float(nsamp);
+    const size_t pix = size_t(lrow) * A.W + col;
+    A.rgb[3 * pix + 0] = accr / fn;
+    A.rgb[3 * pix + 1] = accg / fn;
+    A.rgb[3 * pix + 2] = accb / fn;
+    if (A.id) A.id[pix] = out_id;
+    if (A.t) A.t[pix] = out_t;
+  }
+
+  if (A.stats) {
+    unsigned int v4[4] = {(valid ? 1u : 0u) * (unsigned)nsamp, n_shadow, n_hit, n_occl};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      unsigned int x = v4[k];
+      for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, 64);
+      if (lane == 0 && x) atomicAdd(&A.stats[k], (unsigned long long)x);
+    }
+    if (lane == 0 && n_iter) { // reported as exact_tests / clusters_opened: chain steps of all lanes / 64 x loop iterations
+      atomicAdd(&A.stats[4], (unsigned long long)n_steps);
+      atomicAdd(&A.stats[5], (unsigned long long)n_iter * 64ull);
+    }
+  }
+}
+
+template <bool MULTI>
+__global__ __launch_bounds__(256) void render_bounce_kernel(RenderArgs A) { render_bounce_body<MULTI, false>(A); }
+template <bool MULTI>
+__global__ __launch_bounds__(256) void render_bounce_small_kernel(SmallArgs S) { render_bounce_body<MULTI, true>(S); }
+
+hipError_t launch_render_bounce(const RenderArgs &in, const SmallHost *hs, hipStream_t stream)
+{
+  if (in.max_depth < 1 || in.max_depth > MAX_LEVELS - 1) return hipErrorInvalidValue;
+  const int tiles_x = (in.W + 7) / 8, tiles_y = (in.local_rows + 7) / 8;
   if (tiles_x == 0 || tiles_y == 0) return hipSuccess;
-  hipLaunchKernelGGL(render_bounce_kernel, dim3((tiles_x + 3) / 4, tiles_y), dim3(256), 0, stream, A);
+  const dim3 grid((tiles_x + 3) / 4, tiles_y), block(256);
+  // ablation: MRT_BOUNCE=coupled runs the wave-per-sample kernel, MRT_BOUNCE=nosmall ignores the small-scene
+  // culling data; MRT_BOUNCE_DEEP=n starts a deep iteration as soon as n lanes wait (default 8; 64 = only when
+  // no lane is at level 0)
+  static const char *mode = getenv("MRT_BOUNCE") ? getenv("MRT_BOUNCE") : "";
+  static const int deep = getenv("MRT_BOUNCE_DEEP") ? atoi(getenv("MRT_BOUNCE_DEEP")) : 8;
+  if (hs && std::strcmp(mode, "coupled") != 0 && std::strcmp(mode, "nosmall") != 0) {
+    if (hs->ns != in.sc.ns || hs->nt != in.sc.nt || hs->ns + hs->nt > 64) return hipErrorInvalidValue;
+    SmallArgs S;
+    small_prepare_args(in, *hs, 1, S);
+    S.A.s_cap = deep;
+    if (in.spp > 1) hipLaunchKernelGGL(render_bounce_small_kernel<true>, grid, block, 0, stream, S);
+    else hipLaunchKernelGGL(render_bounce_small_kernel<false>, grid, block, 0, stream, S);
+    return hipGetLastError();
+  }
+  RenderArgs A = in;
+  A.s_cap = deep;
+  { // largest offset of a ray of the padded tile (pixels -1..8 both ways) from the tile's centre ray, rounded up
+    const double hw = 4.5 / A.W, hh = 4.5 / A.H;
+    const double hx[3] = {hw * A.cam.hx, hw * A.cam.hy, hw * A.cam.hz};
+    const double hy[3] = {hh * A.cam.vx, hh * A.cam.vy, hh * A.cam.vz};
+    double p = 0, m = 0;
+    for (int k = 0; k < 3; ++k) { p += (hx[k] + hy[k]) * (hx[k] + hy[k]); m += (hx[k] - hy[k]) * (hx[k] - hy[k]); }
+    A.cone_ext = float(std::sqrt(p > m ? p : m) * 1.001);
+  }
+  if (std::strcmp(mode, "coupled") == 0) hipLaunchKernelGGL(render_bounce_coupled_kernel, grid, block, 0, stream, A);
+  else if (A.spp > 1) hipLaunchKernelGGL(render_bounce_kernel<true>, grid, block, 0, stream, A);
+  else hipLaunchKernelGGL(render_bounce_kernel<false>, grid, block, 0, stream, A);
   return hipGetLastError();
 }
 

@@ -91,10 +91,27 @@ struct SmallHost {
   const int32_t *tri_obj = nullptr; // [nt]
 };
 hipError_t launch_render_small(const RenderArgs &args, const SmallHost &host, hipStream_t stream);
+
+// Kernel arguments of the small-scene kernels: the common ones plus everything a wave needs about "its"
+// primitives (lane = primitive: spheres first, then triangles) before the first exact test, [field][lane]:
+//   sphere lanes:   0-2 centre - origin, 3 primary cull radius, 4-6 origin - centre, 7 |o - c|^2 - r^2, 8 object
+//   triangle lanes: 0-11 four functions (3 edges + plane side) x (W0', Wh, Wv): "W0' + um Wh + vm Wv < 0" at the
+//                   tile centre (um, vm) means that no ray of the padded tile passes that test;
+//                   12 k - n.o, 13 object
+// The exact-test terms (4-7, 12) are computed on the host with the kernels' fp32 operations in the same order.
+enum { SMALL_FIELDS = 14 };
+struct SmallArgs {
+  RenderArgs A;
+  float prm[SMALL_FIELDS][64];
+};
+static_assert(sizeof(SmallArgs) <= 4096, "kernel arguments are limited to 4 KB");
+// fills S for tiles of 8P x 8 pixels (mrt_small.hip): S.A = args with cone_ext set, S.prm
+void small_prepare_args(const RenderArgs &args, const SmallHost &host, int P, SmallArgs &S);
 hipError_t launch_uv_table(float *utab, int nu, int W, float *vtab, int nv, int H, hipStream_t stream);
 
-// bounce chains, max_depth 1..8 (mrt_bounce.hip); a scene with a diffuse object needs args.rng
-hipError_t launch_render_bounce(const RenderArgs &args, hipStream_t stream);
+// bounce chains, max_depth 1..8 (mrt_bounce.hip); a scene with a diffuse object needs args.rng; host != null
+// (scenes of at most 64 primitives) lets the primary rays use the small-scene kernel's per-tile culling
+hipError_t launch_render_bounce(const RenderArgs &args, const SmallHost *host, hipStream_t stream);
 
 // per-pixel XORWOW streams (mrt_rng.hip): jump matrices A^(2^(67+b)), b < RNG_JUMP_MATRICES, 800 words each
 enum { RNG_JUMP_MATRICES = 32 };

@@ -70,19 +70,8 @@ template <> struct VecOf<4> { using f = float4; using i = int4; using nf = nfloa
 
 __device__ __forceinline__ float abs1(float x, float y, float z) { return fabsf(x) + fabsf(y) + fabsf(z); }
 
-// Kernel arguments: the common ones plus everything a wave needs about "its" primitives before the first
-// exact test, [field][lane] -- read straight from the argument segment, one memory round trip after launch:
-//   sphere lanes:   0-2 centre - origin, 3 primary cull radius, 4-6 origin - centre, 7 |o - c|^2 - r^2, 8 object
-//   triangle lanes: 0-11 four functions (3 edges + plane side) x (W0', Wh, Wv): "W0' + um Wh + vm Wv < 0" at the
-//                   tile centre (um, vm) means that no ray of the padded tile passes that test;
-//                   12 k - n.o, 13 object
-// The exact-test terms (4-7, 12) are computed on the host with the kernels' fp32 operations in the same order.
-enum { SMALL_FIELDS = 14 };
-struct SmallArgs {
-  RenderArgs A;
-  float prm[SMALL_FIELDS][64];
-};
-static_assert(sizeof(SmallArgs) <= 4096, "kernel arguments are limited to 4 KB");
+// SmallArgs (mrt_internal.h): the common kernel arguments plus prm[field][lane], read straight from the argument
+// segment, one memory round trip after launch.
 
 template <int P, bool MULTI>
 __device__ __forceinline__ void render_small_body(const SmallArgs &S)
@@ -605,10 +594,9 @@ static void small_primary_functions(const RenderArgs &A, const SmallHost &hs, do
   }
 }
 
-template <int P>
-static hipError_t launch_small(const RenderArgs &in, const SmallHost &hs, hipStream_t stream)
+// Camera-dependent kernel arguments of a small scene for tiles of 8P x 8 pixels: cone extent and prm.
+void small_prepare_args(const RenderArgs &in, const SmallHost &hs, int P, SmallArgs &S)
 {
-  SmallArgs S; // 3.5 KB of kernel arguments
   S.A = in;
   RenderArgs &A = S.A;
   // the padded tile (pixels -1..8P horizontally, -1..8 vertically) around its centre, in u / v units
@@ -632,6 +620,14 @@ static hipError_t launch_small(const RenderArgs &in, const SmallHost &hs, hipStr
     dmax *= 1.001;
   }
   small_primary_functions(A, hs, hw * 1.0001, hh * 1.0001, dmax, S.prm);
+}
+
+template <int P>
+static hipError_t launch_small(const RenderArgs &in, const SmallHost &hs, hipStream_t stream)
+{
+  SmallArgs S; // 3.5 KB of kernel arguments
+  small_prepare_args(in, hs, P, S);
+  RenderArgs &A = S.A;
   // vector stores need every lane's first pixel on a 4P-byte boundary in all three buffers
   const uintptr_t align = 4 * P - 1;
   A.wide = (A.W % P == 0) && ((uintptr_t)A.rgb & align) == 0 && ((uintptr_t)A.id & align) == 0 &&

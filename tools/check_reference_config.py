@@ -22,6 +22,10 @@ st = g["stats"]
 rays = st["primary_rays"] + st["shadow_rays"]
 print("GPU: kernel %.2f ms (wall %.1f ms): %d primary + %d shadow rays -> %.0f Mrays/s" %
       (st["kernel_ms"], wall * 1e3, st["primary_rays"], st["shadow_rays"], rays / st["kernel_ms"] / 1e3), flush=True)
+if st.get("clusters_opened"):
+    print("chain steps %d over %d lane slots: %.1f %% of the lanes busy; %.2f steps per primary ray" %
+          (st["exact_tests"], st["clusters_opened"], 100.0 * st["exact_tests"] / st["clusters_opened"],
+           st["exact_tests"] / st["primary_rays"]), flush=True)
 ora = O.Scene.default()
 bad = 0
 for b in range(bands):

@@ -1,0 +1,39 @@
+"""Stress run for the bounce kernel: random scenes (mixed diffuse / metallic, point and directional lights) at
+random depths, GPU against the oracle, bit for bit.  usage: python tools/stress_bounce.py <first_seed> <count>"""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np
+from raytracing_amd import capi
+import test_gpu_parity as T
+import _oracle as O
+
+first, count = int(sys.argv[1]), int(sys.argv[2])
+ctx = capi.Context(0)
+bad = 0
+t0 = time.time()
+for seed in range(first, first + count):
+    rng = np.random.default_rng(seed)
+    small = seed % 3 != 0
+    spec = T._random_small_scene(seed) if small else T._random_scene(seed)
+    if seed % 5 == 0:
+        spec.mat_kind[:] = capi.MAT_METALLIC
+    W, H = int(rng.integers(3, 24)) * 8 + int(rng.integers(0, 8)), int(rng.integers(2, 16)) * 8 + int(rng.integers(0, 8))
+    depth = int(rng.integers(1, 9))
+    spp = 121 if seed % 11 == 0 else 1
+    if spp == 121:
+        W, H = 40, 24
+    ctx.upload(spec.flatten())
+    cam = spec.cam12(W / H)
+    g = ctx.render(cam, W, H, spp=spp, max_depth=depth)
+    r = O.Scene.from_spec(spec).render(cam, W, H, spp=spp, max_depth=depth, nthreads=16)
+    ok = all(np.array_equal(g[k], r[k], equal_nan=True) for k in ("id", "t", "rgb")) and \
+         all(g["stats"][k] == r["stats"][k] for k in ("primary_rays", "shadow_rays", "hit_pixels", "occluded"))
+    if not ok:
+        bad += 1
+        print("MISMATCH seed", seed, "small" if small else "large", W, H, "spp", spp, "depth", depth,
+              {k: int((g[k] != r[k]).sum()) for k in ("id", "t", "rgb")}, flush=True)
+    if (seed - first) % 50 == 49:
+        print("seed", seed, "done, mismatches so far", bad, "%.0fs" % (time.time() - t0), flush=True)
+print("bounce stress done:", count, "seeds,", bad, "mismatches", flush=True)
+sys.exit(1 if bad else 0)
