@@ -1,12 +1,14 @@
 #!/usr/bin/env python3
 """bench.py -- headline benchmark: Mrays/s (primary + shadow) of the render hot path.
 
-    python bench.py --gpus N --steps K --warmup W [--config C2|C3|C4|C5]
+    python bench.py --gpus N --steps K --warmup W [--config C2|C3|C4|C5|REF]
 
 A "step" is one frame of the configured workload: every rank renders its strips of the frame
 with the HIP back end (scene already resident in HBM), and for N > 1 the strips are gathered
 to rank 0 over RCCL and assembled.  Default workload = BASELINE.json configs[1]: the
 reference's default scene (src/main.cu:183-237) at 1920x1080, 1 spp, primary + shadow rays.
+REF (not a BASELINE config) is what the reference binary itself renders: the same scene at 2048x1024,
+121 samples per pixel, bounce chains to depth 8 (src/main.cu:26, :165).
 
 Prints ONE JSON line on rank 0 (contract in the task statement), including
   roofline      -- dominant kernel (render_kernel) vs the HBM roof, algorithmic bytes/launch
@@ -28,10 +30,17 @@ BYTES_PER_PIXEL = 20         # RGB f32 + id i32 + t f32
 
 
 def build_workload(name):
-    """-> (flat scene, cam12, W, H, flops_per_ray, scene_bytes, oracle scene factory, label)"""
+    """-> (flat scene, cam12, W, H, flops_per_ray, scene_bytes, oracle scene factory, label, spp, max_depth)"""
     from raytracing_amd import capi, scenes
 
-    if name == "C2":
+    spp, max_depth = 1, 0
+    if name == "REF":
+        flat, cam = scenes.default_scene()
+        W, H, spp, max_depth = 2048, 1024, 121, 8
+        cam12 = capi.viewport(cam["look_from"], cam["look_at"], cam["up"], cam["vfov"], W / H)
+        label = "the reference binary's own frame: default main.cu scene, 2048x1024, 121 spp, bounce chains to depth 8"
+        spec = None
+    elif name == "C2":
         flat, cam = scenes.default_scene()
         W, H = 1920, 1080
         cam12 = capi.viewport(cam["look_from"], cam["look_at"], cam["up"], cam["vfov"], W / H)
@@ -53,7 +62,7 @@ def build_workload(name):
         cam12 = spec.cam12(W / H)
     flops = 23 * flat.num_spheres + 36 * flat.num_triangles
     scene_bytes = 16 * flat.num_spheres + 64 * flat.num_triangles
-    return flat, cam12, W, H, flops, scene_bytes, spec, label
+    return flat, cam12, W, H, flops, scene_bytes, spec, label, spp, max_depth
 
 
 def measured_traffic(config, alg_bytes):
@@ -72,7 +81,7 @@ def measured_traffic(config, alg_bytes):
         return None
 
 
-def cpu_baseline(name, spec, flat, cam12, W, H):
+def cpu_baseline(name, spec, flat, cam12, W, H, spp=1, max_depth=0):
     """Time the CPU oracle (a scalar port of the reference path) on this host: bounded sample of the same
     workload.  Brute force costs rays x primitives x (1 + lights), so the sample frame is shrunk (same scene,
     same camera, fewer pixels) until one frame is about 1e9 primitive tests per thread."""
@@ -81,7 +90,7 @@ def cpu_baseline(name, spec, flat, cam12, W, H):
 
     scene = O.Scene.default() if spec is None else O.Scene.from_spec(spec)
     threads = min(16, os.cpu_count() or 1)  # the GPU box's CPU share for one GPU is 16
-    per_ray = max(1, flat.num_spheres + flat.num_triangles) * (1 + flat.num_lights)
+    per_ray = max(1, flat.num_spheres + flat.num_triangles) * (1 + flat.num_lights) * spp
     out = {}
     for label, nt, budget_tests, budget_s in (("1thread", 1, 1.0e9, 6.0), ("threads", threads, 1.0e9 * threads, 10.0)):
         scale = 1
@@ -90,7 +99,7 @@ def cpu_baseline(name, spec, flat, cam12, W, H):
         sw, sh = W // scale, H // scale
         frames, t0, rays = 0, time.perf_counter(), 0
         while True:
-            r = scene.render(cam12, sw, sh, nthreads=nt, want=("rgb", "id", "t"))
+            r = scene.render(cam12, sw, sh, spp=spp, max_depth=max_depth, nthreads=nt, want=("rgb", "id", "t"))
             rays += r["stats"]["primary_rays"] + r["stats"]["shadow_rays"]
             frames += 1
             dt = time.perf_counter() - t0
@@ -147,15 +156,18 @@ def main():
             print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
 
     progress(f"building workload {args.config}")
-    flat, cam12, W, H, flops_ray, scene_bytes, spec, label = build_workload(args.config)
+    flat, cam12, W, H, flops_ray, scene_bytes, spec, label, spp, max_depth = build_workload(args.config)
     heavy = args.config in ("C3", "C4")
+    heavy = heavy or args.config == "REF"
     steps = args.steps if args.steps is not None else (3 if args.config == "C4" else (20 if heavy else 500))
     warmup = args.warmup if args.warmup is not None else (1 if heavy else 50)
 
     fr = multigpu.FrameRenderer(flat, cam12, W, H, rank=rank, num_ranks=world, device=local_rank,
-                                with_ids=not args.no_ids)
+                                with_ids=not args.no_ids, spp=spp, max_depth=max_depth)
     fr.ctx.set_cull(0 if args.brute_force else 1)
     bytes_pp = 12 if args.no_ids else BYTES_PER_PIXEL
+    if max_depth > 0:
+        bytes_pp += 20  # the pixel's random stream: five xorshift words read per frame (mrt_rng.hip)
 
     progress("scene uploaded; counting rays")
     # rays per frame (deterministic for a scene + camera): counted once, outside the timed region
@@ -215,7 +227,12 @@ def main():
         ach_gbs = alg_bytes / (kern_ms * 1e-3) / 1e9
         ach_tf = alg_flops / (kern_ms * 1e-3) / 1e12
         small = flat.num_spheres + flat.num_triangles <= 64
-        if not fr.ctx.cull:
+        if max_depth > 0:
+            kernel_name = "render_bounce_small_kernel" if small else "render_bounce_kernel"
+            kernel_desc = ("render_bounce_small_kernel: 8x8-pixel tiles, every lane walks its pixel's samples and bounce "
+                           "chains as its own state machine (XORWOW stream per pixel); per-tile candidates for primary "
+                           "rays, shadow bundles, brute force further down the chains")
+        elif not fr.ctx.cull:
             kernel_name, kernel_desc = "render_kernel", "render_kernel (brute force: every ray x every primitive)"
         elif small:
             kernel_name = "render_small_kernel"
@@ -223,15 +240,16 @@ def main():
                            "spheres, screen-space edge functions for triangles) + exact tests")
         else:
             kernel_name = "render_cull_kernel"
-            kernel_desc = ("render_cull_kernel: per-tile conservative culling over the Morton-ordered primitive "
+            kernel_desc = ("render_cull_kernel: per-tile conservative culling over the kd-ordered primitive "
                            "hierarchy + exact tests")
         out = {
             "metric": "Mrays/s (primary+shadow) at 1920x1080" if args.config in ("C2", "C5") else
+                      "Mrays/s (primary+shadow at every level) at 2048x1024, 121 spp, depth 8" if args.config == "REF" else
                       "Mrays/s (primary+shadow) at 3840x2160",
             "value": round(value, 3), "unit": "Mrays/s", "n_gpus": world, "steps": steps, "warmup": warmup,
             "ms_per_step": round(ms_per_step, 5), "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{args.config}: {label}", "width": W, "height": H, "spp": 1, "max_depth": 0,
+            "config": {"workload": f"{args.config}: {label}", "width": W, "height": H, "spp": spp, "max_depth": max_depth,
                        "primary_rays": primary, "shadow_rays": shadow,
                        "parallelism": f"{world} GPU(s): 8-row strips round-robin, scene replicated" +
                                       ("" if world == 1 else ", RCCL gather to rank 0 + strip assembly"),
@@ -250,7 +268,7 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             progress(f"GPU done ({ms_per_step:.4f} ms/step); timing the CPU oracle (bounded sample, ~20 s)")
-            out["cpu_baseline"] = cpu_baseline(args.config, spec, flat, cam12, W, H)
+            out["cpu_baseline"] = cpu_baseline(args.config, spec, flat, cam12, W, H, spp, max_depth)
         print(json.dumps(out), flush=True)
 
     fr.close()

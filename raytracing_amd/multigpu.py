@@ -52,12 +52,12 @@ class FrameRenderer:
     """Renders frames of one scene on this rank's GPU and, for N > 1, gathers them to rank 0."""
 
     def __init__(self, flat_scene, cam12, width, height, rank=0, num_ranks=1, device=0, strip_rows=8, spp=1,
-                 with_ids=False):
+                 with_ids=False, max_depth=0):
         import torch
 
         self.torch = torch
         self.rank, self.num_ranks, self.strip_rows = rank, num_ranks, strip_rows
-        self.W, self.H, self.spp = width, height, spp
+        self.W, self.H, self.spp, self.max_depth = width, height, spp, max_depth
         self.cam12 = np.ascontiguousarray(cam12, dtype=np.float32)
         self.dev = torch.device(f"cuda:{device}")
         torch.cuda.set_device(self.dev)
@@ -82,7 +82,7 @@ class FrameRenderer:
         import ctypes as C
         if self._call is None:  # argument structs are built once: a frame is tens of microseconds
             cam = capi.Camera.from12(self.cam12)
-            par = capi.Context._params(self.W, self.H, self.spp, 0, self.rank, self.num_ranks, self.strip_rows)
+            par = capi.Context._params(self.W, self.H, self.spp, self.max_depth, self.rank, self.num_ranks, self.strip_rows)
             self._call = (cam, par, C.byref(cam), C.byref(par), C.c_void_p(self.rgb.data_ptr()),
                           C.c_void_p(self.ids.data_ptr()) if self.ids is not None else None,
                           C.c_void_p(self.tt.data_ptr()) if self.tt is not None else None,
