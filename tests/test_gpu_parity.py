@@ -622,6 +622,55 @@ def test_diffuse_bounces_streams_belong_to_full_frame_pixels(gpu_ctx, kernel_mod
     assert np.array_equal(g["rgb"], r["rgb"]) and np.array_equal(g["id"], r["id"])
 
 
+@pytest.mark.parametrize("W,H,spp", [(1, 1, 1), (7, 5, 121), (33, 17, 1), (129, 8, 1)])
+def test_bounce_ragged_frames(gpu_ctx, kernel_mode, W, H, spp):
+    _only_once(kernel_mode)
+    flat, _ = scenes.default_scene()
+    gpu_ctx.upload(flat)
+    cam = capi.default_viewport(W / H)
+    g = gpu_ctx.render(cam, W, H, spp=spp, max_depth=8)
+    r = O.Scene.default().render(cam, W, H, spp=spp, max_depth=8)
+    assert_frame_parity(g, r, f"bounce {W}x{H} spp {spp}")
+    assert np.array_equal(g["rgb"], r["rgb"])
+    assert_stats_parity(g["stats"], r["stats"])
+
+
+def test_bounce_degenerate_scenes(gpu_ctx, kernel_mode):
+    """Nothing to hit, nothing to light, and one primitive of each kind alone."""
+    _only_once(kernel_mode)
+    cam = capi.default_viewport(2.0)
+    e = np.zeros(0)
+    empty = capi.FlatScene(e, np.zeros((0, 3)), np.zeros((0, 4)), e, np.zeros((16, 0)), e, e, np.zeros((0, 3)),
+                           np.zeros((0, 3)))
+    gpu_ctx.upload(empty)
+    g = gpu_ctx.render(cam, 64, 32, max_depth=8)
+    assert (g["id"] == -1).all() and np.array_equal(g["rgb"], O.Scene().render(cam, 64, 32, max_depth=8)["rgb"])
+    full = _random_small_scene(3)
+    ids = O.Scene.from_spec(full).render(full.cam12(2.0), 96, 48, nthreads=4)["id"]
+    seen = lambda objs: max(objs, key=lambda o: int((ids == o).sum()))   # the most visible one
+    for which in ("sphere", "triangle", "no lights"):
+        spec = _random_small_scene(3)
+        if which == "sphere":
+            k = int(np.nonzero(spec.sphere_obj == seen(spec.sphere_obj))[0][0])
+            spec.mat_kind, spec.mat_rgb = spec.mat_kind[spec.sphere_obj[k:k + 1]], spec.mat_rgb[spec.sphere_obj[k:k + 1]]
+            spec.spheres, spec.sphere_obj = spec.spheres[k:k + 1], np.zeros(1, np.int32)
+            spec.tri_verts, spec.tri_obj = spec.tri_verts[:0], spec.tri_obj[:0]
+        elif which == "triangle":
+            k = int(np.nonzero(spec.tri_obj == seen(spec.tri_obj))[0][0])
+            spec.mat_kind, spec.mat_rgb = spec.mat_kind[spec.tri_obj[k:k + 1]], spec.mat_rgb[spec.tri_obj[k:k + 1]]
+            spec.tri_verts, spec.tri_obj = spec.tri_verts[k:k + 1], np.zeros(1, np.int32)
+            spec.spheres, spec.sphere_obj = spec.spheres[:0], spec.sphere_obj[:0]
+        else:
+            spec.lights = []
+        gpu_ctx.upload(spec.flatten())
+        c = spec.cam12(2.0)
+        g = gpu_ctx.render(c, 96, 48, max_depth=8)
+        r = O.Scene.from_spec(spec).render(c, 96, 48, max_depth=8, nthreads=4)
+        assert (r["id"] >= 0).sum() > 20, which
+        assert_frame_parity(g, r, which)
+        assert_stats_parity(g["stats"], r["stats"])
+
+
 # ------------------------------------------------------------------ strips (multi-GPU partition on one GPU)
 
 @pytest.mark.parametrize("nranks,strip", [(2, 8), (3, 8), (8, 8), (4, 16)])
