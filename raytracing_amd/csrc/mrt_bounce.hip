@@ -300,6 +300,66 @@ __global__ __launch_bounds__(256) void render_bounce_coupled_kernel(RenderArgs A
 // is written and folded through unrolled selects (9 levels x 6 floats).
 // Tiles whose padded cone of primary rays (all 121 sample positions included) misses every primitive bound take a
 // second shortcut: every chain is the sky colour of its primary ray; nothing is tested and nothing is drawn.
+// ---- per-ray walk of the primitive hierarchy (scenes of more than 64 primitives) ---------------------------
+// Bounce rays of neighbouring pixels go everywhere, so there is no tile to cull against; what is left is the ray
+// itself.  Every lane walks the cluster hierarchy of mrt_api.cpp for ITS ray: super-cluster ball, cluster ball
+// (per-lane loads), then the 64 primitives of a cluster it has to open.  The wave moves in lock step -- all
+// lanes look for their next cluster, then all lanes test 64 primitives of their own cluster -- so a lane costs
+// what the lane with the most clusters costs, not what the union of all lanes' clusters costs.  The closest-hit
+// rule is an order-independent minimum over (t, object), and occlusion an order-independent "any", so visiting
+// fewer primitives in another order changes nothing; the ball tests carry the margins of mrt_cull_common.h.
+
+// May the ray from the origin along the unit axis a (within tdist of the origin) touch the ball at w = centre -
+// origin with effective radius reff?  NaN and infinite bounds pass.  The "behind" and "beyond" verdicts rest on the
+// hit point the exact test computes, p = fl(o + t d) with the COMPUTED t in [tmin, tmax]: it lies ahead of the
+// origin and within tmax |d| of it up to its own rounding, 1.2e-7 of |o| + |p - o| -- hence oslack >= 1e-6 |o|_1.
+__device__ __forceinline__ bool ray_may_touch_ball(float wx, float wy, float wz, float reff, float ax, float ay,
+                                                   float az, float tdist, float oslack)
+{
+  const float proj = dot3(wx, wy, wz, ax, ay, az);
+  const float qx = wx - proj * ax, qy = wy - proj * ay, qz = wz - proj * az;
+  const float perp = fast_sqrt(dot3(qx, qy, qz, qx, qy, qz));
+  const float reach = reff + CULL_LEN_SLACK * norm1(wx, wy, wz);
+  if (perp > reach) return false;                   // the line misses the ball
+  const float along = reach + oslack + 1e-6f * reff;
+  if (proj < -along) return false;                  // the ball lies behind the origin: t < 0
+  if (proj - along > tdist) return false;           // ... or beyond the end of the segment
+  return true;
+}
+
+// leaf(first primitive of the lane's cluster, lane takes part) -> lane wants to go on
+template <bool SPHERES, class Leaf>
+__device__ __forceinline__ void walk_per_lane(const float *__restrict__ sclu, int nsc, const float *__restrict__ clu,
+                                              int nc, bool want, float ox, float oy, float oz, float ax, float ay,
+                                              float az, float tdist, Leaf leaf)
+{
+  const float oslack = 1e-6f * norm1(ox, oy, oz);
+  auto touch = [&](const float *__restrict__ b, int n, int i) {
+    const float wx = b[i] - ox, wy = b[n + i] - oy, wz = b[2 * n + i] - oz, R = b[3 * n + i];
+    float reff;
+    if (SPHERES) { // member spheres: sqrt(r^2 + s L^2) <= r + sqrt(s) L, L <= |w| + R (cluster_cull_radius)
+      const float L = fast_sqrt(dot3(wx, wy, wz, wx, wy, wz)) * CULL_REL + R;
+      reff = R * CULL_REL + CULL_DISC_SLACK_SQRT * CULL_REL * L + CULL_ABS;
+    } else {
+      reff = R * CULL_REL + CULL_ABS;
+    }
+    return ray_may_touch_ball(wx, wy, wz, reff, ax, ay, az, tdist, oslack);
+  };
+  int c = -1;
+  bool on = want && nc > 0;
+  while (true) {
+    bool found = false;
+    while (on && !found) { // every lane looks for its next cluster
+      ++c;
+      if (c >= nc) { on = false; break; }
+      if (nsc > 1 && (c & 63) == 0 && !touch(sclu, nsc, c >> 6)) { c += 63; continue; }
+      found = nc == 1 || touch(clu, nc, c);
+    }
+    if (!__any(on)) break;
+    on = leaf(c * 64, on) && on;
+  }
+}
+
 __device__ __forceinline__ const RenderArgs &args_of(const RenderArgs &a) { return a; }
 __device__ __forceinline__ const RenderArgs &args_of(const SmallArgs &s) { return s.A; }
 __device__ __forceinline__ float prm_of(const RenderArgs &, int, int) { return 0.0f; }
@@ -524,9 +584,55 @@ __device__ __forceinline__ void render_bounce_body(const Args &S)
           mask &= mask - 1;
           if (j < ns) hit_sphere(j); else hit_triangle(j - ns);
         }
-      } else {
+      } else if (SMALL) {
         for (int i = 0; i < ns; ++i) hit_sphere(i);
         for (int i = 0; i < nt; ++i) hit_triangle(i);
+      } else {
+        float ax = dx, ay = dy, az = dz;
+        fast_normalize(ax, ay, az);
+        walk_per_lane<true>(sc.sph_sclu, sc.nscs, sc.sph_clu, sc.ncs, act, ox, oy, oz, ax, ay, az, MRT_INF,
+                            [&](int base, bool on) {
+#pragma unroll 4
+          for (int p = 0; p < 64; ++p) { // core/sphere.cuh:32-73, the lane's own sphere
+            const bool ok = on && base + p < ns;
+            const int i = ok ? base + p : 0;
+            const float cx = sc.sph_cx[i], cy = sc.sph_cy[i], cz = sc.sph_cz[i], r = sc.sph_r[i];
+            const int obj = sc.sph_obj[i];
+            const float ocx = ox - cx, ocy = oy - cy, ocz = oz - cz;
+            const float b = dot3(ocx, ocy, ocz, dx, dy, dz);
+            const float c = dot3(ocx, ocy, ocz, ocx, ocy, ocz) - r * r;
+            const float disc = b * b - aa * c;
+            if (ok && disc >= 0.0f) {
+              float t;
+              if (sphere_roots(aa, b, disc, 0.01f, MRT_INF, t)) {
+                if (t < best_t || (t == best_t && t < MRT_INF && obj < best_obj)) { best_t = t; best_obj = obj; best_prim = i; }
+              }
+            }
+          }
+          return true;
+        });
+        walk_per_lane<false>(sc.tri_sclu, sc.nsct, sc.tri_clu, sc.nct, act, ox, oy, oz, ax, ay, az, MRT_INF,
+                             [&](int base, bool on) {
+#pragma unroll 2
+          for (int p = 0; p < 64; ++p) { // core/triangle.cuh:77-103, the lane's own triangle
+            const bool ok = on && base + p < nt;
+            const int i = ok ? base + p : 0;
+            const float4 *q4 = reinterpret_cast<const float4 *>(sc.tri_rec + 16 * size_t(i));
+            const float4 qa = q4[0], qb = q4[1], qc = q4[2], qd = q4[3];
+            const int obj = sc.tri_obj[i];
+            const float rdn = dot3(dx, dy, dz, qa.x, qa.y, qa.z);
+            const float t = (qa.w - dot3(ox, oy, oz, qa.x, qa.y, qa.z)) / rdn;
+            const float px = ox + t * dx, py = oy + t * dy, pz = oz + t * dz;
+            const float e0 = dot3(qb.x, qb.y, qb.z, px, py, pz) - qb.w;
+            const float e1 = dot3(qc.x, qc.y, qc.z, px, py, pz) - qc.w;
+            const float e2 = dot3(qd.x, qd.y, qd.z, px, py, pz) - qd.w;
+            const bool hit = ok & (rdn != 0.0f) & (e0 > -1e-6f) & (e1 > -1e-6f) & (e2 > -1e-6f) & (0.01f <= t) & (t <= MRT_INF);
+            if (hit) {
+              if (t < best_t || (t == best_t && t < MRT_INF && obj < best_obj)) { best_t = t; best_obj = obj; best_prim = ns + i; }
+            }
+          }
+          return true;
+        });
       }
       const bool have_hit = act && best_prim >= 0;
       if (act && depth == 0) { // the ID / t buffers describe the primary hit (of the last sample)
@@ -647,8 +753,47 @@ __device__ __forceinline__ void render_bounce_body(const Args &S)
               if (j < ns) shadow_sphere(j); else shadow_triangle(j - ns);
             }
           } else {
-            for (int i = 0; i < ns && __any(open); ++i) shadow_sphere(i);
-            for (int i = 0; i < nt && __any(open); ++i) shadow_triangle(i);
+            float ax = sdx, ay = sdy, az = sdz;
+            fast_normalize(ax, ay, az);
+            // a point light's shadow ray ends at the light (t <= 1): nothing beyond |sd| (+ 0.1 %) matters
+            const float tdist = lkind == 0 ? MRT_INF : fast_sqrt(sa) * 1.001f;
+            walk_per_lane<true>(sc.sph_sclu, sc.nscs, sc.sph_clu, sc.ncs, open, hpx, hpy, hpz, ax, ay, az, tdist,
+                                [&](int base, bool on) {
+#pragma unroll 4
+              for (int p = 0; p < 64; ++p) {
+                const bool ok = on && base + p < ns;
+                const int i = ok ? base + p : 0;
+                const float cx = sc.sph_cx[i], cy = sc.sph_cy[i], cz = sc.sph_cz[i], r = sc.sph_r[i];
+                const float ocx = hpx - cx, ocy = hpy - cy, ocz = hpz - cz;
+                const float b = dot3(ocx, ocy, ocz, sdx, sdy, sdz);
+                const float c = dot3(ocx, ocy, ocz, ocx, ocy, ocz) - r * r;
+                const float disc = b * b - sa * c;
+                if (ok && open && disc >= 0.0f) {
+                  float t;
+                  if (sphere_roots(sa, b, disc, 1e-3f, tl, t)) open = false;
+                }
+              }
+              return open;
+            });
+            walk_per_lane<false>(sc.tri_sclu, sc.nsct, sc.tri_clu, sc.nct, open, hpx, hpy, hpz, ax, ay, az, tdist,
+                                 [&](int base, bool on) {
+#pragma unroll 2
+              for (int p = 0; p < 64; ++p) {
+                const bool ok = on && base + p < nt;
+                const int i = ok ? base + p : 0;
+                const float4 *q4 = reinterpret_cast<const float4 *>(sc.tri_rec + 16 * size_t(i));
+                const float4 qa = q4[0], qb = q4[1], qc = q4[2], qd = q4[3];
+                const float rdn = dot3(sdx, sdy, sdz, qa.x, qa.y, qa.z);
+                const float t = (qa.w - dot3(hpx, hpy, hpz, qa.x, qa.y, qa.z)) / rdn;
+                const float px = hpx + t * sdx, py = hpy + t * sdy, pz = hpz + t * sdz;
+                const float e0 = dot3(qb.x, qb.y, qb.z, px, py, pz) - qb.w;
+                const float e1 = dot3(qc.x, qc.y, qc.z, px, py, pz) - qc.w;
+                const float e2 = dot3(qd.x, qd.y, qd.z, px, py, pz) - qd.w;
+                const bool h = ok & (rdn != 0.0f) & (e0 > -1e-6f) & (e1 > -1e-6f) & (e2 > -1e-6f) & (1e-3f <= t) & (t <= tl);
+                if (open && h) open = false;
+              }
+              return open;
+            });
           }
           if (need) { n_shadow++; if (!open) n_occl++; }
           if (open) {

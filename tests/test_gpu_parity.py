@@ -671,6 +671,27 @@ def test_bounce_degenerate_scenes(gpu_ctx, kernel_mode):
         assert_stats_parity(g["stats"], r["stats"])
 
 
+@pytest.mark.parametrize("which", ["spheres 10k", "terrain 10k", "lights 512"])
+def test_bounces_in_large_scenes_walk_the_hierarchy(gpu_ctx, kernel_mode, which):
+    """More than 64 primitives: every lane walks the cluster hierarchy for its own ray (mrt_bounce.hip,
+    walk_per_lane) -- 157 clusters in 3 super-clusters for the 10k scenes, point lights (bounded shadow segments)
+    for the third.  Mixed materials, depth 4."""
+    _only_once(kernel_mode)
+    spec = {"spheres 10k": lambda: scenes.sphere_field(10000), "terrain 10k": lambda: scenes.triangle_terrain(100, 50),
+            "lights 512": scenes.light_stress}[which]()
+    gpu_ctx.upload(spec.flatten())
+    W, H = (96, 54) if which != "lights 512" else (64, 36)
+    cam = spec.cam12(W / H)
+    g = gpu_ctx.render(cam, W, H, max_depth=4)
+    r = O.Scene.from_spec(spec).render(cam, W, H, max_depth=4, nthreads=8)
+    assert_frame_parity(g, r, which)
+    assert np.array_equal(g["rgb"], r["rgb"])
+    assert_stats_parity(g["stats"], r["stats"])
+    assert g["stats"]["hit_pixels"] > 1000
+    if which != "terrain 10k":   # (the terrain's upward normals fail the reference's L.N test: no shadow rays at all)
+        assert g["stats"]["shadow_rays"] > g["stats"]["hit_pixels"] // 4
+
+
 # ------------------------------------------------------------------ strips (multi-GPU partition on one GPU)
 
 @pytest.mark.parametrize("nranks,strip", [(2, 8), (3, 8), (8, 8), (4, 16)])
