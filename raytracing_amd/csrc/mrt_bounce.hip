@@ -430,8 +430,8 @@ __device__ __forceinline__ void render_bounce_body(const Args &S)
   //      every side (covers the sub-pixel sample offsets), against every primitive bound; as in mrt_cull.hip ----
   bool tile_has_candidates;
   unsigned long long primary_mask = ~0ull; // SMALL: primitives (bit = lane) a primary ray of the tile may hit
+  float cax, cay, caz, cosT, sinT;         // the tile's cone of primary rays: unit axis, half-angle
   {
-    float cax, cay, caz, cosT, sinT;
     const float rw = fast_rcp(float(A.W)), rh = fast_rcp(float(A.H));
     const float um = (float(tile_x * 8) + 3.5f) * rw, vm = (float(grow0) + 3.5f) * rh;
     cax = ((cam.ux + um * cam.hx) + vm * cam.vx) - cam.ox;
@@ -587,6 +587,52 @@ __device__ __forceinline__ void render_bounce_body(const Args &S)
       } else if (SMALL) {
         for (int i = 0; i < ns; ++i) hit_sphere(i);
         for (int i = 0; i < nt; ++i) hit_triangle(i);
+      } else if (primary_iter) {
+        // large scene, all active lanes at level 0: their rays lie in the tile's cone, so the wave culls the
+        // hierarchy once for all of them (lane-parallel ball tests, as in mrt_cull.hip) and runs the exact test
+        // of a surviving primitive for every lane
+        walk_hierarchy<true>(sc.sph_sclu, sc.nscs, sc.sph_clu, sc.ncs, lane,
+                             [&](float x, float y, float z, float R) {
+                               const float wx = x - cam.ox, wy = y - cam.oy, wz = z - cam.oz;
+                               const float L = fast_sqrt(dot3(wx, wy, wz, wx, wy, wz)) * CULL_REL + R;
+                               return ball_may_touch_cone(wx, wy, wz, cluster_cull_radius(R, L), cax, cay, caz, cosT, sinT);
+                             },
+                             [&](int base) {
+          const int i = base + lane;
+          bool pass = false;
+          if (i < ns) {
+            const float r = sc.sph_r[i];
+            const float wx = sc.sph_cx[i] - cam.ox, wy = sc.sph_cy[i] - cam.oy, wz = sc.sph_cz[i] - cam.oz;
+            pass = ball_may_touch_cone(wx, wy, wz, sphere_cull_radius(r * r, dot3(wx, wy, wz, wx, wy, wz)), cax, cay, caz,
+                                       cosT, sinT);
+          }
+          unsigned long long mask = __ballot(pass);
+          while (mask) {
+            const int j = __builtin_ctzll(mask);
+            mask &= mask - 1;
+            hit_sphere(base + j);
+          }
+          return true;
+        });
+        walk_hierarchy<true>(sc.tri_sclu, sc.nsct, sc.tri_clu, sc.nct, lane,
+                             [&](float x, float y, float z, float R) {
+                               return ball_may_touch_cone(x - cam.ox, y - cam.oy, z - cam.oz, R * CULL_REL + CULL_ABS, cax, cay,
+                                                          caz, cosT, sinT);
+                             },
+                             [&](int base) {
+          const int i = base + lane;
+          bool pass = false;
+          if (i < nt)
+            pass = ball_may_touch_cone(sc.tri_bx[i] - cam.ox, sc.tri_by[i] - cam.oy, sc.tri_bz[i] - cam.oz,
+                                       sc.tri_br[i] * CULL_REL + CULL_ABS, cax, cay, caz, cosT, sinT);
+          unsigned long long mask = __ballot(pass);
+          while (mask) {
+            const int j = __builtin_ctzll(mask);
+            mask &= mask - 1;
+            hit_triangle(base + j);
+          }
+          return true;
+        });
       } else {
         float ax = dx, ay = dy, az = dz;
         fast_normalize(ax, ay, az);
@@ -679,12 +725,23 @@ __device__ __forceinline__ void render_bounce_body(const Args &S)
         // SMALL: ball around the hit points of this iteration (centre = the first one); with a light it spans the
         // bundle of shadow rays that each primitive's bound is tested against (mrt_cull_common.h), one primitive
         // per lane.  Valid for any set of hit points; tight in primary iterations, loose in deep ones.
+        // Large scenes, primary iterations: the same bundle (centre = centre of the hit points' box), with the slab
+        // of mrt_cull.hip per light, against the hierarchy.
         Bundle B;
-        if (SMALL) {
-          const int first = __builtin_ctzll(__ballot(have_hit));
-          B.mx = bcast(hpx, first); B.my = bcast(hpy, first); B.mz = bcast(hpz, first);
-          const float ex = hpx - B.mx, ey = hpy - B.my, ez = hpz - B.mz;
-          B.rho = fast_sqrt(wave_max(have_hit ? dot3(ex, ey, ez, ex, ey, ez) : 0.0f)) * CULL_REL + CULL_ABS;
+        const bool tile_shadows = SMALL || primary_iter;
+        float bex = 0.0f, bey = 0.0f, bez = 0.0f; // this lane's hit point relative to the bundle's centre
+        if (tile_shadows) {
+          if (SMALL) {
+            const int first = __builtin_ctzll(__ballot(have_hit));
+            B.mx = bcast(hpx, first); B.my = bcast(hpy, first); B.mz = bcast(hpz, first);
+          } else {
+            const float big = 3.0e38f;
+            B.mx = 0.5f * (wave_min(have_hit ? hpx : big) + wave_max(have_hit ? hpx : -big));
+            B.my = 0.5f * (wave_min(have_hit ? hpy : big) + wave_max(have_hit ? hpy : -big));
+            B.mz = 0.5f * (wave_min(have_hit ? hpz : big) + wave_max(have_hit ? hpz : -big));
+          }
+          bex = hpx - B.mx; bey = hpy - B.my; bez = hpz - B.mz;
+          B.rho = fast_sqrt(wave_max(have_hit ? dot3(bex, bey, bez, bex, bey, bez) : 0.0f)) * CULL_REL + CULL_ABS;
         }
         for (int li = 0; li < sc.nl; ++li) {
           const int lkind = sc.light_kind[li];
@@ -752,6 +809,52 @@ __device__ __forceinline__ void render_bounce_body(const Args &S)
               mask &= mask - 1;
               if (j < ns) shadow_sphere(j); else shadow_triangle(j - ns);
             }
+          } else if (primary_iter) {
+            if (__any(open)) {
+              B.point = lkind != 0;
+              if (lkind == 0) { B.Dx = -lvx; B.Dy = -lvy; B.Dz = -lvz; }
+              else { B.Dx = lvx - B.mx; B.Dy = lvy - B.my; B.Dz = lvz - B.mz; }
+              B.DD = dot3(B.Dx, B.Dy, B.Dz, B.Dx, B.Dy, B.Dz);
+              bundle_make_slab(B, cax, cay, caz, bex, bey, bez, have_hit);
+              walk_hierarchy<true>(sc.sph_sclu, sc.nscs, sc.sph_clu, sc.ncs, lane,
+                                   [&](float x, float y, float z, float R) {
+                                     const float wx = x - B.mx, wy = y - B.my, wz = z - B.mz;
+                                     const float Lm = fast_sqrt(dot3(wx, wy, wz, wx, wy, wz)) * CULL_REL + B.rho + R;
+                                     return bundle_may_touch(B, x, y, z, cluster_cull_radius(R, Lm));
+                                   },
+                                   [&](int base) {
+                const int i = base + lane;
+                bool pass = false;
+                if (i < ns) {
+                  const float cx = sc.sph_cx[i], cy = sc.sph_cy[i], cz = sc.sph_cz[i], r = sc.sph_r[i];
+                  const float wx = cx - B.mx, wy = cy - B.my, wz = cz - B.mz;
+                  const float Lm = fast_sqrt(dot3(wx, wy, wz, wx, wy, wz)) * CULL_REL + B.rho; // >= |hit point - centre|
+                  pass = bundle_may_touch(B, cx, cy, cz, sphere_cull_radius(r * r, Lm * Lm));
+                }
+                unsigned long long mask = __ballot(pass);
+                while (mask && __any(open)) {
+                  const int j = __builtin_ctzll(mask);
+                  mask &= mask - 1;
+                  shadow_sphere(base + j);
+                }
+                return __any(open) != 0;
+              });
+            }
+            if (__any(open))
+              walk_hierarchy<true>(sc.tri_sclu, sc.nsct, sc.tri_clu, sc.nct, lane,
+                                   [&](float x, float y, float z, float R) { return bundle_may_touch(B, x, y, z, R); },
+                                   [&](int base) {
+                const int i = base + lane;
+                bool pass = false;
+                if (i < nt) pass = bundle_may_touch(B, sc.tri_bx[i], sc.tri_by[i], sc.tri_bz[i], sc.tri_br[i]);
+                unsigned long long mask = __ballot(pass);
+                while (mask && __any(open)) {
+                  const int j = __builtin_ctzll(mask);
+                  mask &= mask - 1;
+                  shadow_triangle(base + j);
+                }
+                return __any(open) != 0;
+              });
           } else {
             float ax = sdx, ay = sdy, az = sdz;
             fast_normalize(ax, ay, az);
@@ -905,8 +1008,10 @@ __device__ __forceinline__ void render_bounce_body(const Args &S)
   }
 }
 
+// three waves per SIMD (at most 168 registers): left alone the compiler takes 172 and loses a wave
 template <bool MULTI>
-__global__ __launch_bounds__(256) void render_bounce_kernel(RenderArgs A) { render_bounce_body<MULTI, false>(A); }
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8)))
+void render_bounce_kernel(RenderArgs A) { render_bounce_body<MULTI, false>(A); }
 template <bool MULTI>
 __global__ __launch_bounds__(256) void render_bounce_small_kernel(SmallArgs S) { render_bounce_body<MULTI, true>(S); }
 

@@ -32,53 +32,6 @@
 
 namespace mrt {
 
-// ---- primitive-side hierarchy walk ---------------------------------------------------------------------
-// Primitives are stored in kd order; runs of 64 primitives have a bounding ball ("cluster"), runs of 64
-// clusters another one ("super-cluster").  A wave walks the hierarchy with lane-parallel tests at every
-// level: 64 super-clusters per step, then the 64 clusters of each surviving super-cluster, then
-// body(first primitive of the cluster) for each surviving cluster.  A level with a single entry is not
-// tested (tiny scenes: C2).  body returns false to stop the walk (shadow early-out).
-template <class Test>
-__device__ __forceinline__ unsigned long long level_mask(const float *__restrict__ balls, int n, int begin, int lane,
-                                                         Test test)
-{
-  if (n == 1) return 1ull;
-  const int i = begin + lane;
-  bool pass = false;
-  if (i < min(n, begin + 64)) pass = test(balls[i], balls[n + i], balls[2 * n + i], balls[3 * n + i]);
-  return __ballot(pass);
-}
-
-template <bool HIER, class Test, class Body>
-__device__ __forceinline__ void walk_hierarchy(const float *__restrict__ sclu, int nsc, const float *__restrict__ clu,
-                                               int nc, int lane, Test test, Body body)
-{
-  if (!HIER) { // at most one cluster per primitive type (C2): nothing to walk
-    if (nc > 0) body(0);
-    return;
-  }
-  for (int sb = 0; sb < nsc; sb += 64) {
-    unsigned long long smask = level_mask(sclu, nsc, sb, lane, test);
-    while (smask) {
-      const int cb = (sb + __builtin_ctzll(smask)) * 64;
-      smask &= smask - 1;
-      unsigned long long cmask = level_mask(clu, nc, cb, lane, test);
-      while (cmask) {
-        const int base = (cb + __builtin_ctzll(cmask)) * 64;
-        cmask &= cmask - 1;
-        if (!body(base)) return;
-      }
-    }
-  }
-}
-
-// effective radius of a ball of radius R containing spheres seen from distance <= Lmax:
-// a member sphere's cull radius is sqrt(r^2 + s L^2) <= r + sqrt(s) L
-__device__ __forceinline__ float cluster_cull_radius(float R, float Lmax)
-{
-  return R * CULL_REL + CULL_DISC_SLACK_SQRT * CULL_REL * Lmax + CULL_ABS;
-}
-
 template <int P> struct CVec;
 template <> struct CVec<1> { using f = float; using i = int; };
 template <> struct CVec<2> { typedef float f __attribute__((ext_vector_type(2))); typedef int i __attribute__((ext_vector_type(2))); };
