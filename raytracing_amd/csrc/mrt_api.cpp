@@ -146,7 +146,8 @@ static hipError_t launch_by_mode(mrt_ctx *ctx, mrt::RenderArgs &A, hipStream_t s
       mrt::rng_seed_state(ctx->rng_seed, v, &A.rng_d);
       A.rng = ctx->rng_mem; A.rng_stride = ctx->rng_n;
     }
-    const bool small = (long)A.sc.ns + A.sc.nt <= 64;
+    // MRT_OPT_CULL = 0 keeps the small-scene culling data out of it (every ray walks the hierarchy: cross-check)
+    const bool small = (long)A.sc.ns + A.sc.nt <= 64 && ctx->cull != 0;
     mrt::SmallHost hs;
     if (small) {
       hs.ns = (int)ctx->small_sph_obj.size(); hs.nt = (int)ctx->small_tri_obj.size();

@@ -485,7 +485,6 @@ __device__ __forceinline__ void render_small_body(const SmallArgs &S)
   if (A.wide && valid_row && col0 + P <= A.W) {
     // the lane's 3P floats / P ints / P floats are contiguous and 4P-byte aligned (launcher checks W and pointers)
     using VF = typename VecOf<P>::f;
-    using VI = typename VecOf<P>::i;
     float o[3 * P];
 #pragma unroll
     for (int p = 0; p < P; ++p) { o[3 * p] = accr[p]; o[3 * p + 1] = accg[p]; o[3 * p + 2] = accb[p]; }

@@ -474,8 +474,11 @@ def test_sliver_with_open_edge_planes(gpu_ctx):
 # ------------------------------------------------------------------ mirror chains (max_depth > 0)
 
 def _only_once(kernel_mode):
-    if kernel_mode != "brute":
-        pytest.skip("max_depth > 0 always runs render_bounce_kernel: one pass is enough")
+    """max_depth > 0 always runs the bounce kernel, in one of two forms: with the small-scene culling data
+    (scenes of at most 64 primitives, any kernel mode but 0) or without (mode 0, and every larger scene: each ray
+    walks the primitive hierarchy).  Two passes cover both."""
+    if kernel_mode not in ("brute", "small"):
+        pytest.skip("max_depth > 0: the bounce kernel has two forms, selected by modes 0 and 5")
 
 
 @pytest.mark.parametrize("depth", [1, 2, 8])

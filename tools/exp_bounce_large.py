@@ -1,5 +1,4 @@
-"""Kernel time of bounce chains in the large synthetic scenes (depth 8, 1 spp).  MRT_BOUNCE=coupled selects the
-brute-force kernel for comparison.  usage: python tools/exp_bounce_large.py [C3|C4s|C5] [W H]"""
+"""Kernel time of bounce chains in the large synthetic scenes (depths 0, 1, 8; 1 spp).  usage: python tools/exp_bounce_large.py [C3|C4s|C5] [W H]"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -15,4 +14,4 @@ for depth in (0, 1, 8):
     g = ctx.render(cam, W, H, max_depth=depth)
     st = g["stats"]
     print("%s %dx%d depth %d (%s): kernel %.2f ms, %d primary + %d shadow rays" %
-          (cfg, W, H, depth, os.environ.get("MRT_BOUNCE", "default"), st["kernel_ms"], st["primary_rays"], st["shadow_rays"]), flush=True)
+          (cfg, W, H, depth, os.environ.get("MRT_CULL", "default"), st["kernel_ms"], st["primary_rays"], st["shadow_rays"]), flush=True)

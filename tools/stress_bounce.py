@@ -25,6 +25,7 @@ for seed in range(first, first + count):
         W, H = 40, 24
     ctx.upload(spec.flatten())
     cam = spec.cam12(W / H)
+    ctx.set_cull(0 if seed % 2 else 1)   # small scenes: with / without the small-scene culling data
     g = ctx.render(cam, W, H, spp=spp, max_depth=depth)
     r = O.Scene.from_spec(spec).render(cam, W, H, spp=spp, max_depth=depth, nthreads=16)
     ok = all(np.array_equal(g[k], r[k], equal_nan=True) for k in ("id", "t", "rgb")) and \
