@@ -19,7 +19,7 @@ LIGHT_DIRECTIONAL, LIGHT_POINT = 0, 1
 # every symbol include/mrt.h declares (tests check the library exports all of them)
 MRT_SYMBOLS = [
     "mrt_device_count", "mrt_ctx_create", "mrt_ctx_destroy", "mrt_ctx_set_option", "mrt_last_error", "mrt_status_string",
-    "mrt_triangle_bound", "mrt_rng_state", "mrt_scene_upload", "mrt_local_rows", "mrt_render", "mrt_render_device", "mrt_assemble_strips",
+    "mrt_triangle_bound", "mrt_rng_state", "mrt_host_alloc", "mrt_host_free", "mrt_scene_upload", "mrt_local_rows", "mrt_render", "mrt_render_device", "mrt_assemble_strips",
     "mrt_intersect",
 ]
 
@@ -100,6 +100,8 @@ def libmrt():
         L.mrt_scene_upload.argtypes = [C.c_void_p, C.POINTER(SceneDesc)]
         L.mrt_triangle_bound.argtypes = [_f, _f]
         L.mrt_rng_state.argtypes = [C.c_uint64, C.c_uint32, C.c_void_p]
+        L.mrt_host_alloc.argtypes = [C.c_size_t, C.POINTER(C.c_void_p)]
+        L.mrt_host_free.argtypes = [C.c_void_p]
         L.mrt_local_rows.argtypes = [C.c_int32, C.POINTER(Partition), _i32]
         L.mrt_render.argtypes = [C.c_void_p, C.POINTER(Camera), C.POINTER(RenderParams), C.c_void_p, C.c_void_p,
                                  C.c_void_p, C.POINTER(Stats)]
@@ -177,6 +179,36 @@ def rng_state(seed, subsequence):
     if rc != 0:
         raise MrtError(f"mrt_rng_state: {rc}")
     return out
+
+
+class HostBuffer:
+    """Page-locked host memory from mrt_host_alloc, viewed as numpy arrays; free() or the garbage collector
+    returns it."""
+
+    def __init__(self, nbytes):
+        self.nbytes = int(nbytes)
+        ptr = C.c_void_p()
+        rc = libmrt().mrt_host_alloc(self.nbytes, C.byref(ptr))
+        if rc != 0 or not ptr.value:
+            raise MrtError(f"mrt_host_alloc({nbytes}): {rc}")
+        self.ptr = ptr.value
+
+    def view(self, dtype, shape, offset=0):
+        n = int(np.prod(shape)) * np.dtype(dtype).itemsize
+        assert offset + n <= self.nbytes
+        buf = (C.c_char * n).from_address(self.ptr + offset)
+        return np.frombuffer(buf, dtype=dtype).reshape(shape)
+
+    def free(self):
+        if self.ptr:
+            libmrt().mrt_host_free(self.ptr)
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
 
 
 def directional_light_dir(d):
@@ -356,6 +388,19 @@ class Context:
                                 C.byref(st) if want_stats else None)
         self._check(rc, "mrt_render")
         return {"rgb": rgb, "id": ids, "t": t, "stats": st.as_dict() if want_stats else None}
+
+    def render_into(self, cam12, W, H, rgb, ids=None, t=None, spp=1, max_depth=0):
+        """Blocking render of the whole frame into caller-owned host arrays (e.g. views of page-locked memory
+        from host_alloc): rgb float32 [H, W, 3], ids int32 [H, W], t float32 [H, W]."""
+        assert rgb.dtype == np.float32 and rgb.size == H * W * 3 and rgb.flags["C_CONTIGUOUS"]
+        cam = Camera.from12(cam12)
+        p = self._params(W, H, spp, max_depth, 0, 1, 8)
+        st = Stats()
+        rc = self._L.mrt_render(self._h, C.byref(cam), C.byref(p), rgb.ctypes.data,
+                                ids.ctypes.data if ids is not None else None,
+                                t.ctypes.data if t is not None else None, C.byref(st))
+        self._check(rc, "mrt_render")
+        return st.as_dict()
 
     def render_device(self, cam12, W, H, rgb_ptr, id_ptr=None, t_ptr=None, stats_ptr=None, stream=None, spp=1,
                       max_depth=0, rank=0, num_ranks=1, strip_rows=8):

@@ -730,16 +730,18 @@ __device__ __forceinline__ void render_bounce_body(const Args &S)
   }
 
   if (A.stats) {
+    // counters are spread over stats_slots copies: same-address atomics cost ~12 ns each, one after the other
+    unsigned long long *st = A.stats + 8u * ((blockIdx.x + 7u * blockIdx.y) & (unsigned)(A.stats_slots - 1));
     unsigned int v4[4] = {(valid ? 1u : 0u) * (unsigned)nsamp, n_shadow, n_hit, n_occl};
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       unsigned int x = v4[k];
       for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, 64);
-      if (lane == 0 && x) atomicAdd(&A.stats[k], (unsigned long long)x);
+      if (lane == 0 && x) atomicAdd(&st[k], (unsigned long long)x);
     }
     if (lane == 0 && n_iter) { // reported as exact_tests / clusters_opened: chain steps of all lanes / 64 x loop iterations
-      atomicAdd(&A.stats[4], (unsigned long long)n_steps);
-      atomicAdd(&A.stats[5], (unsigned long long)n_iter * 64ull);
+      atomicAdd(&st[4], (unsigned long long)n_steps);
+      atomicAdd(&st[5], (unsigned long long)n_iter * 64ull);
     }
   }
 }

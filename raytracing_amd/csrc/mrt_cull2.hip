@@ -555,12 +555,14 @@ __global__ __launch_bounds__(WAVES * 64) void render_cull2_kernel(RenderArgs A)
   }
 
   if (A.stats) {
+    // counters are spread over stats_slots copies: same-address atomics cost ~12 ns each, one after the other
+    unsigned long long *st = A.stats + 8u * ((blockIdx.x + 7u * blockIdx.y) & (unsigned)(A.stats_slots - 1));
     unsigned int v4[4] = {n_pix * (unsigned)nsamp, n_shadow, n_hit, n_occl};
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       unsigned int x = v4[k];
       for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, 64);
-      if (lane == 0 && x) atomicAdd(&A.stats[k], (unsigned long long)x);
+      if (lane == 0 && x) atomicAdd(&st[k], (unsigned long long)x);
     }
   }
 }

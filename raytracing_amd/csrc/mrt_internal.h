@@ -63,7 +63,8 @@ struct RenderArgs {
   float *rgb;                       // [local_rows*W*3]
   int32_t *id;                      // [local_rows*W] or null
   float *t;                         // [local_rows*W] or null
-  unsigned long long *stats;        // 4 counters or null
+  unsigned long long *stats;        // stats_slots x 8 counters (the host adds the slots up) or null
+  int32_t stats_slots;              // power of two; 1 for a caller's 8-counter buffer
   // LDS plan (filled by the launcher)
   int32_t resident;                 // whole scene staged once
   int32_t s_cap, t_cap;             // primitives per LDS chunk

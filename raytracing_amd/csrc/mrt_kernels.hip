@@ -599,6 +599,8 @@ __global__ __launch_bounds__(256) void render_kernel(RenderArgs A)
   }
 
   if (A.stats) {
+    // counters are spread over stats_slots copies: same-address atomics cost ~12 ns each, one after the other
+    unsigned long long *st = A.stats + 8u * ((blockIdx.x + 7u * blockIdx.y) & (unsigned)(A.stats_slots - 1));
     // wave reduction, one atomic per wave (only on the stats path, never in timed loops)
     unsigned int npix = 0;
 #pragma unroll
@@ -608,7 +610,7 @@ __global__ __launch_bounds__(256) void render_kernel(RenderArgs A)
     for (int k = 0; k < 4; ++k) {
       unsigned int x = v4[k];
       for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, 64);
-      if (lane == 0 && x) atomicAdd(&A.stats[k], (unsigned long long)x);
+      if (lane == 0 && x) atomicAdd(&st[k], (unsigned long long)x);
     }
   }
 }

@@ -4,6 +4,7 @@ Bar (BASELINE.json north_star): hit mask, object IDs and t bit-identical; RGB wi
 per channel after clamping to [0,1] (we also assert the max abs float difference, which is
 expected to be exactly 0 because both sides run the same fp32 operation order with FMA
 contraction off)."""
+import ctypes as C
 import json
 import os
 
@@ -744,6 +745,28 @@ def test_device_render_and_strip_assembly(gpu_ctx):
     torch.cuda.synchronize()
     assert np.array_equal(frame.cpu().numpy(), full["rgb"])
     assert np.array_equal(frame_id.cpu().numpy(), full["id"])
+
+
+def test_render_into_page_locked_host_memory(gpu_ctx):
+    """mrt_host_alloc / mrt_host_free (the replacement of the managed ImageBuffer, container/alloc.cuh:30): a frame
+    rendered into page-locked memory equals the one rendered into numpy's pageable arrays."""
+    flat, _ = scenes.default_scene()
+    gpu_ctx.upload(flat)
+    W, H = 320, 200
+    cam = capi.default_viewport(W / H)
+    ref = gpu_ctx.render(cam, W, H)
+    hb = capi.HostBuffer(W * H * 20)
+    rgb = hb.view(np.float32, (H, W, 3))
+    ids = hb.view(np.int32, (H, W), offset=W * H * 12)
+    t = hb.view(np.float32, (H, W), offset=W * H * 16)
+    st = gpu_ctx.render_into(cam, W, H, rgb, ids, t)
+    assert np.array_equal(rgb, ref["rgb"]) and np.array_equal(ids, ref["id"]) and np.array_equal(t, ref["t"])
+    assert_stats_parity(st, ref["stats"])
+    del rgb, ids, t
+    hb.free()
+    empty = C.c_void_p(1)
+    assert capi.libmrt().mrt_host_alloc(0, C.byref(empty)) == 0 and not empty.value
+    assert capi.libmrt().mrt_host_free(None) == 0
 
 
 def test_error_paths(gpu_ctx):
