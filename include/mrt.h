@@ -180,7 +180,8 @@ int mrt_render(mrt_ctx *ctx, const mrt_camera *cam, const mrt_render_params *par
  * Asynchronous render into DEVICE buffers on a caller-supplied HIP stream
  * (hipStream_t passed as void*; NULL = HIP's default stream, as in HIP itself).  Same layout
  * as mrt_render.  stats_dev, if not NULL, points to 8 device uint64 that receive
- * primary/shadow/hit/occluded counts, exact-test and opened-cluster counts (2 spare).  The caller synchronises.
+ * primary/shadow/hit/occluded counts, exact-test and opened-cluster counts (2 spare), written by a small kernel
+ * that follows the render on the same stream.  The caller synchronises.
  */
 int mrt_render_device(mrt_ctx *ctx, const mrt_camera *cam, const mrt_render_params *params, void *rgb_dev,
                       void *id_dev, void *t_dev, void *stats_dev, void *stream);

@@ -775,11 +775,15 @@ int mrt_render_device(mrt_ctx *ctx, const mrt_camera *cam, const mrt_render_para
   if (rc != MRT_OK) return rc;
   if (!rgb_dev) return fail(ctx, MRT_ERR_INVALID, "rgb buffer is required");
   A.rgb = (float *)rgb_dev; A.id = (int32_t *)id_dev; A.t = (float *)t_dev;
-  A.stats = (unsigned long long *)stats_dev;
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   hipStream_t st = (hipStream_t)stream; // NULL = HIP's default stream, as everywhere in HIP
-  if (A.stats) HIP_TRY(ctx, hipMemsetAsync(A.stats, 0, 8 * sizeof(unsigned long long), st));
+  if (stats_dev) { // counted in the context's spread copies, then added up into the caller's eight words
+    A.stats = ctx->stats_dev;
+    A.stats_slots = STATS_SLOTS;
+    HIP_TRY(ctx, hipMemsetAsync(A.stats, 0, STATS_SLOTS * 8 * sizeof(unsigned long long), st));
+  }
   HIP_TRY(ctx, launch_by_mode(ctx, A, st));
+  if (stats_dev) HIP_TRY(ctx, mrt::launch_stats_reduce(ctx->stats_dev, STATS_SLOTS, (unsigned long long *)stats_dev, st));
   return MRT_OK;
 }
 

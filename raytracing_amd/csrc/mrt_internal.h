@@ -127,6 +127,8 @@ hipError_t launch_render(const RenderArgs &args, hipStream_t stream);
 hipError_t launch_intersect(int prim_kind, const float *prim_dev, const float *rays_dev, float tmin, float tmax,
                             int64_t n, uint8_t *hit_dev, float *t_dev, float *point_dev, float *normal_dev,
                             hipStream_t stream);
+hipError_t launch_stats_reduce(const unsigned long long *slots, int nslots, unsigned long long *out8,
+                               hipStream_t stream);
 hipError_t launch_assemble(const uint32_t *gathered, size_t rank_stride_elems, uint32_t *frame, int W, int H,
                            int elem_dwords, int nranks, int strip_rows, hipStream_t stream);
 

@@ -738,4 +738,31 @@ hipError_t launch_assemble(const uint32_t *gathered, size_t rank_stride_elems, u
   return hipGetLastError();
 }
 
+// The render kernels spread their ray counters over `slots` copies of 8 (same-address atomics serialise); this
+// adds the copies up into the caller's 8 counters.  One workgroup: thread t owns copy t, t + 256, ...
+__global__ __launch_bounds__(256) void stats_reduce_kernel(const unsigned long long *__restrict__ slots, int nslots,
+                                                           unsigned long long *__restrict__ out8)
+{
+  __shared__ unsigned long long part[4][8];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  unsigned long long acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  for (int s = threadIdx.x; s < nslots; s += 256)
+#pragma unroll
+    for (int k = 0; k < 8; ++k) acc[k] += slots[size_t(s) * 8 + k];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    unsigned long long x = acc[k];
+    for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, 64);
+    if (lane == 0) part[wave][k] = x;
+  }
+  __syncthreads();
+  if (threadIdx.x < 8) out8[threadIdx.x] = part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x];
+}
+
+hipError_t launch_stats_reduce(const unsigned long long *slots, int nslots, unsigned long long *out8, hipStream_t stream)
+{
+  hipLaunchKernelGGL(stats_reduce_kernel, dim3(1), dim3(256), 0, stream, slots, nslots, out8);
+  return hipGetLastError();
+}
+
 } // namespace mrt
