@@ -769,6 +769,27 @@ def test_render_into_page_locked_host_memory(gpu_ctx):
     assert capi.libmrt().mrt_host_free(None) == 0
 
 
+def test_cpp_host_layer_unit_tests_and_cli(gpu_ctx, tmp_path):
+    """The C++ host layer end to end: raytracing_amd/host/test/host_tests.cpp (the reference's unit tests against
+    this API + the 640x480 anchors, through rt::hit / rt::Renderer) and the `raytracing` CLI writing a .hdr."""
+    import subprocess
+    lib = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "raytracing_amd", "lib")
+    out = subprocess.run([os.path.join(lib, "host_tests")], capture_output=True, text=True, timeout=100)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-500:]
+    assert ", 0 failed" in out.stdout
+    hdr = tmp_path / "frame.hdr"
+    out = subprocess.run([os.path.join(lib, "raytracing"), str(hdr), "96", "48", "121", "8"], capture_output=True, text=True,
+                         timeout=100)
+    assert out.returncode == 0, out.stdout[-1000:] + out.stderr[-500:]
+    assert "page-locked" in out.stdout
+    data = hdr.read_bytes()
+    head = b"#?RADIANCE\nFORMAT=32-bit_rle_rgbe\n\n-Y 48 +X 96\n"
+    assert data.startswith(head) and len(data) == len(head) + 96 * 48 * 4
+    # the CLI flips the image (row 0 of the file = top of the picture = the sky's upper part: bluer than white)
+    px = np.frombuffer(data[len(head):], dtype=np.uint8).reshape(48, 96, 4)
+    assert px[0, 0, 2] >= px[0, 0, 0]
+
+
 def test_error_paths(gpu_ctx):
     ctx = capi.Context(0)
     with pytest.raises(capi.MrtError, match="no scene"):
