@@ -224,17 +224,50 @@ __device__ __forceinline__ void render_bounce_body(const Args &S)
     if (own_s) { pbx = sc.sph_cx[lane]; pby = sc.sph_cy[lane]; pbz = sc.sph_cz[lane]; pbr = sc.sph_r[lane]; }
     else if (own_t) { const int k = lane - ns; pbx = sc.tri_bx[k]; pby = sc.tri_by[k]; pbz = sc.tri_bz[k]; pbr = sc.tri_br[k]; }
   }
-  // primitive data comes through wave-uniform scalar loads (keeping a small scene in registers and broadcasting
-  // it with readlane was measured slower: 16 readlanes per triangle against one s_load_dwordx16)
+  // SMALL: every wave keeps its own copy of the scene in LDS (at most 64 records of 20 words: spheres cx, cy, cz,
+  // r, object; triangles the 16 floats + object), written once by the owning lanes and read back with one address
+  // for the whole wave (broadcast).  The loops below then wait ~100 cycles of LDS latency per primitive instead of
+  // a scalar-cache round trip, and nothing competes for scalar registers.  Larger scenes: scalar loads.
+  __shared__ float scene_lds[SMALL ? 4 : 1][SMALL ? 64 * 20 : 1];
+  if (SMALL && tile_has_candidates) {
+    float *rec = &scene_lds[wave][lane * 20];
+    if (own_s) {
+      rec[0] = pbx; rec[1] = pby; rec[2] = pbz; rec[3] = pbr;
+      rec[16] = __int_as_float(sc.sph_obj[lane]);
+    } else if (own_t) {
+      const float4 *q4 = reinterpret_cast<const float4 *>(sc.tri_rec + 16 * size_t(lane - ns));
+#pragma unroll
+      for (int k = 0; k < 4; ++k) reinterpret_cast<float4 *>(rec)[k] = q4[k];
+      rec[16] = __int_as_float(sc.tri_obj[lane - ns]);
+    }
+    __builtin_amdgcn_wave_barrier(); // written and read by this wave only
+  }
   auto sphere_of = [&](int i, float &cx, float &cy, float &cz, float &r, int &obj) {
-    cx = sc.sph_cx[i]; cy = sc.sph_cy[i]; cz = sc.sph_cz[i]; r = sc.sph_r[i];
-    obj = sc.sph_obj[i];
+    if (SMALL) {
+      const float *rec = &scene_lds[wave][i * 20];
+      const float4 a = *reinterpret_cast<const float4 *>(rec);
+      cx = a.x; cy = a.y; cz = a.z; r = a.w;
+      obj = __float_as_int(rec[16]);
+    } else {
+      cx = sc.sph_cx[i]; cy = sc.sph_cy[i]; cz = sc.sph_cz[i]; r = sc.sph_r[i];
+      obj = sc.sph_obj[i];
+    }
   };
   auto triangle_of = [&](int i, float (&q)[16], int &obj) {
-    const float *m = sc.tri_rec + 16 * size_t(i);
+    if (SMALL) {
+      const float *rec = &scene_lds[wave][(ns + i) * 20];
 #pragma unroll
-    for (int k = 0; k < 16; ++k) q[k] = m[k];
-    obj = sc.tri_obj[i];
+      for (int k = 0; k < 4; ++k) {
+        const float4 a = reinterpret_cast<const float4 *>(rec)[k];
+        q[4 * k] = a.x; q[4 * k + 1] = a.y; q[4 * k + 2] = a.z; q[4 * k + 3] = a.w;
+      }
+      obj = __float_as_int(rec[16]);
+    } else {
+      const float *m = sc.tri_rec + 16 * size_t(i);
+#pragma unroll
+      for (int k = 0; k < 16; ++k) q[k] = m[k];
+      obj = sc.tri_obj[i];
+    }
   };
 
   if (!tile_has_candidates) {
