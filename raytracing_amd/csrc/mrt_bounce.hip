@@ -42,7 +42,7 @@ constexpr int MAX_LEVELS = 9; // depths 0..8
 // second shortcut: every chain is the sky colour of its primary ray; nothing is tested and nothing is drawn.
 // ---- per-ray walk of the primitive hierarchy (scenes of more than 64 primitives) ---------------------------
 // Bounce rays of neighbouring pixels go everywhere, so there is no tile to cull against; what is left is the ray
-// itself.  Every lane walks the cluster hierarchy of mrt_api.cpp for ITS ray: super-cluster ball, cluster ball
+// itself.  Every lane walks the cluster hierarchy of mrt_scene_build.h for ITS ray: super-cluster ball, cluster ball
 // (per-lane loads), then the 64 primitives of a cluster it has to open.  The wave moves in lock step -- all
 // lanes look for their next cluster, then all lanes test 64 primitives of their own cluster -- so a lane costs
 // what the lane with the most clusters costs, not what the union of all lanes' clusters costs.  The closest-hit

@@ -4,8 +4,8 @@
 // results of that loop depend only on the primitives a ray can actually hit, so this kernel first asks,
 // once per 8x8 pixel tile (one wave64), which primitives can be hit by ANY ray of the tile:
 //
-//   * primitives are stored in kd order (mrt_api.cpp) with bounding balls for every 64 primitives (cluster) and every
-//     64 clusters (super-cluster), built at upload (mrt_api.cpp).  At each level the 64 lanes each take a
+//   * primitives are stored in kd order (mrt_scene_build.h) with bounding balls for every 64 primitives (cluster) and every
+//     64 clusters (super-cluster), built at upload (mrt_scene_build.h).  At each level the 64 lanes each take a
 //     DIFFERENT ball (coalesced SoA loads: 64 balls per instruction) and test it against a bound of the
 //     tile's ray bundle
 //       - primary rays:   a circular cone from the camera origin around the tile's four corner rays

@@ -7,7 +7,7 @@
 namespace mrt {
 
 // Scene as it lives in HBM: pure SoA streams, one allocation.  Primitives of a type are stored in kd
-// order of their bound centres (mrt_api.cpp); *_obj carries the object number every result is reported in.
+// order of their bound centres (mrt_scene_build.h); *_obj carries the object number every result is reported in.
 struct DevScene {
   // spheres: 4 streams of ns floats (core/sphere.cuh:116-117) + object numbers
   const float *sph_cx, *sph_cy, *sph_cz, *sph_r;
@@ -17,13 +17,13 @@ struct DevScene {
   const float *tri;
   const int32_t *tri_obj;
   // conservative bounding spheres of the regions the triangle hit test accepts (built at upload,
-  // mrt_api.cpp tri_bound); radius +inf = never culled.  4 streams of nt floats.
+  // mrt_scene_build.h tri_bound); radius +inf = never culled.  4 streams of nt floats.
   const float *tri_bx, *tri_by, *tri_bz, *tri_br;
   // the same 16 floats per triangle, contiguous (64 B records), for wave-uniform fetches of the few
   // triangles that survive culling (one s_load_dwordx16 instead of 16 strided scalar loads)
   const float *tri_rec;
   // shadow-ray edge functions of the first nls lights, [light][23][triangle] (scenes of <= 64 primitives only;
-  // mrt_api.cpp shadow_functions, used by mrt_small.hip)
+  // mrt_scene_build.h shadow_functions, used by mrt_small.hip)
   const float *tri_shfn;
   int32_t nls;
   // bounding balls of runs of 64 consecutive primitives (primitives are stored in kd order):

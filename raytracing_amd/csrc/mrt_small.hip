@@ -20,7 +20,7 @@
 //     kernel arguments.  The same construction bounds shadow rays: e_i at the point where the shadow ray of
 //     hit point p meets the plane is affine in p, for directional and for point lights, and is bounded over
 //     the ball around the tile's hit points; these functions depend on scene and lights only and are built
-//     at upload (mrt_api.cpp, shadow_functions);
+//     at upload (mrt_scene_build.h, shadow_functions);
 //   * u = col / W and v = row / H come from two tables computed once per frame size with the same IEEE
 //     division (uv_table_kernel) instead of 1 + P divisions per lane.
 //
