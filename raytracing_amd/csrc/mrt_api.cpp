@@ -52,6 +52,9 @@ struct mrt_ctx {
   uint32_t *rng_mem = nullptr;
   uint32_t rng_n = 0;
   uint64_t rng_seed = 1984, rng_built_seed = 0; // cuda_utils/curand_state.cuh:22
+  // scratch of the bounce kernel's tile ordering (mrt_bounce.hip), grown on demand
+  uint32_t *bounce_scratch = nullptr;
+  size_t bounce_scratch_words = 0;
 
 };
 
@@ -161,7 +164,22 @@ static hipError_t launch_by_mode(mrt_ctx *ctx, mrt::RenderArgs &A, hipStream_t s
       hs.sph = ctx->small_sph.data(); hs.sph_obj = ctx->small_sph_obj.data();
       hs.tri16 = ctx->small_tri16.data(); hs.tri_obj = ctx->small_tri_obj.data();
     }
-    return mrt::launch_render_bounce(A, small ? &hs : nullptr, st);
+    uint32_t *scratch = nullptr;
+    if (small && A.spp > 1) {
+      const size_t need = mrt::bounce_scratch_words(A.W, A.local_rows);
+      if (ctx->bounce_scratch_words < need) {
+        hipError_t e;
+        if (ctx->bounce_scratch) {
+          if ((e = hipDeviceSynchronize()) != hipSuccess) return e; // a render in flight may still read the old one
+          (void)hipFree(ctx->bounce_scratch);
+          ctx->bounce_scratch = nullptr; ctx->bounce_scratch_words = 0;
+        }
+        if ((e = hipMalloc((void **)&ctx->bounce_scratch, need * sizeof(uint32_t))) != hipSuccess) return e;
+        ctx->bounce_scratch_words = need;
+      }
+      scratch = ctx->bounce_scratch;
+    }
+    return mrt::launch_render_bounce(A, small ? &hs : nullptr, scratch, st);
   }
   int mode = ctx->cull;
   const bool small = (long)A.sc.ns + A.sc.nt <= 64;
@@ -265,6 +283,7 @@ int mrt_ctx_destroy(mrt_ctx *ctx)
   if (ctx->uv_mem) (void)hipFree(ctx->uv_mem);
   if (ctx->rng_mem) (void)hipFree(ctx->rng_mem);
   if (ctx->rng_jump) (void)hipFree(ctx->rng_jump);
+  if (ctx->bounce_scratch) (void)hipFree(ctx->bounce_scratch);
   if (ctx->out_mem) (void)hipFree(ctx->out_mem);
   if (ctx->stats_dev) (void)hipFree(ctx->stats_dev);
   if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);

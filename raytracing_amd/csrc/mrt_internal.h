@@ -76,6 +76,8 @@ struct RenderArgs {
   // and the Weyl counter every stream starts with; null when no stream is needed
   const uint32_t *rng;
   uint32_t rng_stride, rng_d;
+  // bounce kernel: wave w renders tile tile_order[w] (null: tile w); tiles are numbered row by row
+  const uint32_t *tile_order;
 };
 
 hipError_t launch_render_cull(const RenderArgs &args, hipStream_t stream);
@@ -112,7 +114,9 @@ hipError_t launch_uv_table(float *utab, int nu, int W, float *vtab, int nv, int 
 
 // bounce chains, max_depth 1..8 (mrt_bounce.hip); a scene with a diffuse object needs args.rng; host != null
 // (scenes of at most 64 primitives) lets the primary rays use the small-scene kernel's per-tile culling
-hipError_t launch_render_bounce(const RenderArgs &args, const SmallHost *host, hipStream_t stream);
+// scratch (device, 4 * tiles + 64 words, or null) lets the launcher order the tiles by predicted cost
+hipError_t launch_render_bounce(const RenderArgs &args, const SmallHost *host, uint32_t *scratch, hipStream_t stream);
+inline size_t bounce_scratch_words(int W, int local_rows) { return 4 * (size_t)((W + 7) / 8) * ((local_rows + 7) / 8) + 64; }
 
 // per-pixel XORWOW streams (mrt_rng.hip): jump matrices A^(2^(67+b)), b < RNG_JUMP_MATRICES, 800 words each
 enum { RNG_JUMP_MATRICES = 32 };
