@@ -975,7 +975,7 @@ hipError_t launch_render_bounce(const RenderArgs &in, const SmallHost *hs, uint3
     const double hy[3] = {hh * A.cam.vx, hh * A.cam.vy, hh * A.cam.vz};
     double p = 0, m = 0;
     for (int k = 0; k < 3; ++k) { p += (hx[k] + hy[k]) * (hx[k] + hy[k]); m += (hx[k] - hy[k]) * (hx[k] - hy[k]); }
-    A.cone_ext = float(std::sqrt(p > m ? p : m) * 1.001);
+    A.cone_ext = float(std::sqrt(p > m ? p : m) * 1.001) + 2.0f * camera_rounding(A.cam); // the ray's and the centre's
   }
   if (A.spp > 1) hipLaunchKernelGGL(render_bounce_kernel<true>, grid, block, 0, stream, A);
   else hipLaunchKernelGGL(render_bounce_kernel<false>, grid, block, 0, stream, A);

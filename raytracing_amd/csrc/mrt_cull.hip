@@ -520,7 +520,7 @@ static hipError_t launch_cull(RenderArgs &A, hipStream_t stream)
     const double hy[3] = {hh * A.cam.vx, hh * A.cam.vy, hh * A.cam.vz};
     double p = 0, m = 0;
     for (int k = 0; k < 3; ++k) { p += (hx[k] + hy[k]) * (hx[k] + hy[k]); m += (hx[k] - hy[k]) * (hx[k] - hy[k]); }
-    A.cone_ext = float(std::sqrt(p > m ? p : m) * 1.001);
+    A.cone_ext = float(std::sqrt(p > m ? p : m) * 1.001) + 2.0f * camera_rounding(A.cam); // the ray's and the centre's
   }
   const uintptr_t align = 4 * P - 1;
   A.wide = (A.W % P == 0) && ((uintptr_t)A.rgb & align) == 0 && ((uintptr_t)A.id & align) == 0 &&

@@ -78,7 +78,7 @@ __device__ __forceinline__ Cone make_cone(const DevCamera &cam, float um, float 
   c.az = ((cam.uz + um * cam.hz) + vm * cam.vz) - cam.oz;
   const float inv = fast_rsq(dot3(c.ax, c.ay, c.az, c.ax, c.ay, c.az));
   c.ax *= inv; c.ay *= inv; c.az *= inv;
-  c.sinT = ext * inv * (1.0f + 1e-4f) + 1e-6f;
+  c.sinT = (ext + 2.0f * camera_rounding(cam)) * inv * (1.0f + 1e-4f) + 1e-6f; // + the rounding of ray and centre
   c.cosT = fast_sqrt(fmaxf(1.0f - c.sinT * c.sinT, 0.0f)) * (1.0f - 1e-5f) - 1e-6f;
   if (!(c.sinT < 0.99f) || !(c.cosT > 0.0f)) { c.cosT = -1.0f; c.sinT = 0.0f; } // cannot cull
   return c;

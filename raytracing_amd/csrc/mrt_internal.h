@@ -3,6 +3,7 @@
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <math.h>
 
 namespace mrt {
 
@@ -51,6 +52,20 @@ struct DevCamera {
   float vx, vy, vz;
   float ux, uy, uz; // up_left
 };
+
+// Bound on the absolute fp32 rounding error of a primary ray direction, ((ul + u h) + v vv) - o with u, v in
+// about [0, 1]: five roundings, each relative to at most the sum of the magnitudes involved.  Negligible next to a
+// pixel while the camera sits within a few thousand units of the world origin; far out (|o| ~ 1e5) the computed
+// directions are coarser than the pixel grid and the culling cones and edge functions have to allow for it.
+#if defined(__HIPCC__)
+__host__ __device__
+#endif
+inline float camera_rounding(const DevCamera &c)
+{
+  const float mag = fabsf(c.ux) + fabsf(c.uy) + fabsf(c.uz) + fabsf(c.hx) + fabsf(c.hy) + fabsf(c.hz) + fabsf(c.vx) +
+                    fabsf(c.vy) + fabsf(c.vz) + fabsf(c.ox) + fabsf(c.oy) + fabsf(c.oz);
+  return 9.6e-7f * mag; // 16 x 2^-24
+}
 
 struct RenderArgs {
   DevScene sc;

@@ -563,6 +563,7 @@ static void small_primary_functions(const RenderArgs &A, const SmallHost &hs, do
   auto dot = [](const double *a, const double *b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; };
   auto n1f = [](const double *a) { return std::fabs(a[0]) + std::fabs(a[1]) + std::fabs(a[2]); };
   const double o1 = n1f(o);
+  const double cam_delta = 2.0 * camera_rounding(A.cam);
   for (int j = 0; j < nt; ++j) {
     const float *q = tri16 + 16 * j;
     float (*pri)[64] = prm;
@@ -585,7 +586,8 @@ static void small_primary_functions(const RenderArgs &A, const SmallHost &hs, do
       }
       const double Wh = dot(w, h), Wv = dot(w, vv), W0 = dot(w, base);
       const double ext = std::fabs(Wh) * hu + std::fabs(Wv) * hv;
-      const double W0p = W0 + ext + dmax * K + 1e-6 * (std::fabs(W0) + ext); // the last term: float rounding below
+      // + the rounding of the ray direction itself (camera_rounding), seen through w
+      const double W0p = W0 + ext + dmax * K + n1f(w) * cam_delta + 1e-6 * (std::fabs(W0) + ext); // last term: float rounding below
       pri[3 * i + 0][col] = (float)W0p;
       pri[3 * i + 1][col] = (float)Wh;
       pri[3 * i + 2][col] = (float)Wv;
@@ -609,7 +611,7 @@ void small_prepare_args(const RenderArgs &in, const SmallHost &hs, int P, SmallA
     const double hy[3] = {hh * A.cam.vx, hh * A.cam.vy, hh * A.cam.vz};
     double p = 0, m = 0;
     for (int k = 0; k < 3; ++k) { p += (hx[k] + hy[k]) * (hx[k] + hy[k]); m += (hx[k] - hy[k]) * (hx[k] - hy[k]); }
-    A.cone_ext = float(std::sqrt(p > m ? p : m) * 1.001);
+    A.cone_ext = float(std::sqrt(p > m ? p : m) * 1.001) + 2.0f * camera_rounding(A.cam); // the ray's and the centre's
     // largest 1-norm of a ray direction over the padded frame: |d|_1 is convex in (u, v), so at a corner
     for (int c = 0; c < 4; ++c) {
       const double u = (c & 1) ? 1.0 + hw : -hw, v = (c & 2) ? 1.0 + hh : -hh;

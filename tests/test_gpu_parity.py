@@ -472,6 +472,31 @@ def test_sliver_with_open_edge_planes(gpu_ctx):
 
 
 
+def _moved(spec, shift):
+    """The whole scene (geometry, point lights, camera) moved by shift * (0.6, -0.4, 1)."""
+    off = np.array([0.6, -0.4, 1.0]) * shift
+    spec.spheres = (spec.spheres.astype(np.float64) + np.append(off, 0.0)).astype(np.float32)
+    spec.tri_verts = (spec.tri_verts.astype(np.float64) + off).astype(np.float32)
+    spec.lights = [(k, tuple(np.asarray(v) + off) if k == capi.LIGHT_POINT else v, c) for k, v, c in spec.lights]
+    spec.camera["look_from"] = tuple(np.asarray(spec.camera["look_from"], np.float64) + off)
+    spec.camera["look_at"] = tuple(np.asarray(spec.camera["look_at"], np.float64) + off)
+    return spec
+
+
+@pytest.mark.parametrize("seed,small,W,H", [(93, True, 304, 237), (137, False, 168, 209)])
+def test_scene_far_from_the_world_origin(gpu_ctx, seed, small, W, H):
+    """1e5 units out, fp32 ray directions ((ul + u h) + v vv) - o are coarser than the pixel grid: the culling cones
+    and edge functions must allow for the rounding of the rays themselves (camera_rounding, mrt_internal.h).
+    Found by tools/stress_parity.py with a shift of 1e5 (58 mismatching seeds of 4000 before the fix)."""
+    spec = _moved(_random_small_scene(seed) if small else _random_scene(seed), 1.0e5)
+    gpu_ctx.upload(spec.flatten())
+    cam = spec.cam12(W / H)
+    g = gpu_ctx.render(cam, W, H)
+    r = O.Scene.from_spec(spec).render(cam, W, H, nthreads=8)
+    assert_frame_parity(g, r, spec.name)
+    assert_stats_parity(g["stats"], r["stats"])
+
+
 # ------------------------------------------------------------------ mirror chains (max_depth > 0, SURVEY 8(f).1)
 
 def _only_once(kernel_mode):

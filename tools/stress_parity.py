@@ -1,5 +1,7 @@
 """Stress run: many random scenes, every culling kernel against the brute-force kernel, bit for bit.
-usage: python tools/stress_parity.py <first_seed> <count> [small|large|both]"""
+usage: python tools/stress_parity.py <first_seed> <count> [small|large|both] [shift [scale]]
+shift / scale: the whole scene (geometry, point lights, camera) is scaled and then moved by shift * (0.6, -0.4, 1)
+-- far from the world origin fp32 positions get coarse, which is what the culling margins have to survive."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -9,6 +11,21 @@ import test_gpu_parity as T
 
 first, count = int(sys.argv[1]), int(sys.argv[2])
 which = sys.argv[3] if len(sys.argv) > 3 else "both"
+shift = float(sys.argv[4]) if len(sys.argv) > 4 else 0.0
+scale = float(sys.argv[5]) if len(sys.argv) > 5 else 1.0
+
+
+def transform(spec):
+    if shift == 0.0 and scale == 1.0:
+        return spec
+    off = np.array([0.6, -0.4, 1.0]) * shift
+    spec.spheres = (spec.spheres.astype(np.float64) * scale + np.append(off, 0.0)).astype(np.float32)
+    spec.tri_verts = (spec.tri_verts.astype(np.float64) * scale + off).astype(np.float32)
+    spec.lights = [(k, tuple(np.asarray(v) * scale + off) if k == capi.LIGHT_POINT else v, c) for k, v, c in spec.lights]
+    spec.camera["look_from"] = tuple(np.asarray(spec.camera["look_from"], np.float64) * scale + off)
+    spec.camera["look_at"] = tuple(np.asarray(spec.camera["look_at"], np.float64) * scale + off)
+    return spec
+
 ctx = capi.Context(0)
 bad = 0
 t0 = time.time()
@@ -16,7 +33,7 @@ for seed in range(first, first + count):
     for kind in ("small", "large"):
         if which not in (kind, "both"):
             continue
-        spec = T._random_small_scene(seed) if kind == "small" else T._random_scene(seed)
+        spec = transform(T._random_small_scene(seed) if kind == "small" else T._random_scene(seed))
         rng = np.random.default_rng(seed)
         W, H = int(rng.integers(3, 40)) * 8, int(rng.integers(2, 30)) * 8 + int(rng.integers(0, 8))
         spp = 121 if seed % 23 == 0 else 1
