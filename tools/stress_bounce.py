@@ -1,15 +1,18 @@
 """Stress run for the bounce kernel: random scenes (mixed diffuse / metallic, point and directional lights) at
-random depths, GPU against the oracle, bit for bit.  usage: python tools/stress_bounce.py <first_seed> <count> [shift]   (shift: the scene moved by shift * (0.6, -0.4, 1))"""
+random depths, GPU against the oracle, bit for bit.  usage: python tools/stress_bounce.py <first_seed> <count> [shift [wild]]
+shift: the scene moved by shift * (0.6, -0.4, 1); wild (any fourth argument): stress_common.make_wild per seed."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, os.path.join(ROOT, "tools"))
 import numpy as np
 from raytracing_amd import capi
 import test_gpu_parity as T
 import _oracle as O
+from stress_common import moved, make_wild
 
 first, count = int(sys.argv[1]), int(sys.argv[2])
 shift = float(sys.argv[3]) if len(sys.argv) > 3 else 0.0
+wild = len(sys.argv) > 4
 ctx = capi.Context(0)
 bad = 0
 t0 = time.time()
@@ -19,8 +22,9 @@ for seed in range(first, first + count):
     spec = T._random_small_scene(seed) if small else T._random_scene(seed)
     if seed % 5 == 0:
         spec.mat_kind[:] = capi.MAT_METALLIC
-    if shift:
-        spec = T._moved(spec, shift)
+    if wild:
+        spec = make_wild(spec, seed)
+    spec = moved(spec, shift)
     W, H = int(rng.integers(3, 24)) * 8 + int(rng.integers(0, 8)), int(rng.integers(2, 16)) * 8 + int(rng.integers(0, 8))
     depth = int(rng.integers(1, 9))
     spp = 121 if seed % 11 == 0 else 1
