@@ -32,22 +32,29 @@ for seed in range(first, first + count):
         spec = moved(spec, shift, scale)
         rng = np.random.default_rng(seed)
         W, H = int(rng.integers(3, 40)) * 8, int(rng.integers(2, 30)) * 8 + int(rng.integers(0, 8))
+        if seed % 4 == 3:   # ragged widths, tiny frames
+            W, H = int(rng.integers(1, 330)), int(rng.integers(1, 250))
+        part = (0, 1, 8)
+        if seed % 7 == 5:   # one rank's strips of a partition
+            nr = int(rng.integers(2, 9)); part = (int(rng.integers(0, nr)), nr, 8 * int(rng.integers(1, 4)))
         spp = 121 if seed % 23 == 0 else 1
         if spp == 121:
             W, H = 64, 40
         ctx.upload(spec.flatten())
         cam = spec.cam12(W / H)
-        ctx.set_cull(0); ref = ctx.render(cam, W, H, spp=spp)
+        ctx.set_cull(0); ref = ctx.render(cam, W, H, spp=spp, rank=part[0], num_ranks=part[1], strip_rows=part[2])
         if os.environ.get("STRESS_ORACLE"):   # also the brute-force kernel against the CPU oracle
             import _oracle as O
             r = O.Scene.from_spec(spec).render(cam, W, H, spp=spp, nthreads=16)
+            rows = capi.local_row_index(H, *part)
+            r = {k: r[k][rows] for k in ("id", "t", "rgb")}
             ok = all(np.array_equal(ref[k], r[k], equal_nan=True) for k in ("id", "t", "rgb"))
             if not ok:
                 bad += 1
                 print("MISMATCH seed", seed, kind, "brute force vs ORACLE", W, H, spp,
                       {k: int((~((ref[k] == r[k]) | (np.isnan(ref[k]) & np.isnan(r[k])))).sum()) for k in ("id", "t", "rgb")}, flush=True)
         for mode in ((5, 2) if kind == "small" else (2, 4)):
-            ctx.set_cull(mode); g = ctx.render(cam, W, H, spp=spp)
+            ctx.set_cull(mode); g = ctx.render(cam, W, H, spp=spp, rank=part[0], num_ranks=part[1], strip_rows=part[2])
             ok = all(np.array_equal(g[k], ref[k], equal_nan=True) for k in ("id", "t", "rgb")) and \
                  all(g["stats"][k] == ref["stats"][k] for k in ("primary_rays", "shadow_rays", "hit_pixels", "occluded"))
             if not ok:
