@@ -30,13 +30,18 @@ for seed in range(first, first + count):
     spp = 121 if seed % 11 == 0 else 1
     if spp == 121:
         W, H = 40, 24
+    part = (0, 1, 8)
+    if seed % 7 == 5:   # one rank's strips of a partition: a pixel's random stream is its index in the FULL frame
+        nr = int(rng.integers(2, 9)); part = (int(rng.integers(0, nr)), nr, 8 * int(rng.integers(1, 4)))
     ctx.upload(spec.flatten())
     cam = spec.cam12(W / H)
     ctx.set_cull(0 if seed % 2 else 1)   # small scenes: with / without the small-scene culling data
-    g = ctx.render(cam, W, H, spp=spp, max_depth=depth)
+    g = ctx.render(cam, W, H, spp=spp, max_depth=depth, rank=part[0], num_ranks=part[1], strip_rows=part[2])
     r = O.Scene.from_spec(spec).render(cam, W, H, spp=spp, max_depth=depth, nthreads=16)
+    rows = capi.local_row_index(H, *part)
+    r = {k: (r[k][rows] if k != "stats" else r[k]) for k in r}
     ok = all(np.array_equal(g[k], r[k], equal_nan=True) for k in ("id", "t", "rgb")) and \
-         all(g["stats"][k] == r["stats"][k] for k in ("primary_rays", "shadow_rays", "hit_pixels", "occluded"))
+         (part[1] > 1 or all(g["stats"][k] == r["stats"][k] for k in ("primary_rays", "shadow_rays", "hit_pixels", "occluded")))
     if not ok:
         bad += 1
         print("MISMATCH seed", seed, "small" if small else "large", W, H, "spp", spp, "depth", depth,
