@@ -931,8 +931,11 @@ __global__ __launch_bounds__(256) void bounce_order_kernel(const uint32_t *__res
 template <bool MULTI>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8)))
 void render_bounce_kernel(RenderArgs A) { render_bounce_body<MULTI, false>(A); }
+// four waves per SIMD (128 registers, ~30 spilled: 5.85 ms on the reference's frame against 6.05 with the 157 the
+// compiler takes by itself; five waves spill far too much: 10 ms)
 template <bool MULTI>
-__global__ __launch_bounds__(256) void render_bounce_small_kernel(SmallArgs S) { render_bounce_body<MULTI, true>(S); }
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8)))
+void render_bounce_small_kernel(SmallArgs S) { render_bounce_body<MULTI, true>(S); }
 
 hipError_t launch_render_bounce(const RenderArgs &in, const SmallHost *hs, uint32_t *scratch, hipStream_t stream)
 {
