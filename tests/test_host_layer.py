@@ -107,6 +107,16 @@ def test_cpp_host_layer_compiles_standalone(tmp_path):
                            str(src)])
 
 
+def test_cpp_host_layer_cpu_tests():
+    """raytracing_amd/host/test/host_cpu_tests.cpp: Transform / apply_transform, Interval modes, work partition,
+    ImageBuffer ownership and flip, default-scene flattening -- the C++ host layer without a GPU."""
+    exe = os.path.join(ROOT, "raytracing_amd", "lib", "host_cpu_tests")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "raytracing_amd", "host")], stdout=subprocess.DEVNULL)
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=60)
+    assert out.returncode == 0 and ", 0 failed" in out.stdout, out.stdout + out.stderr
+
+
 def test_triangle_bound_of_a_sliver_with_open_edge_planes_is_unbounded():
     """A sliver whose float edge planes do not close: the pairwise intersection of edge planes 0 and 1 lies
     1e-8 (relative) OUTSIDE edge plane 2, so the region the hit test accepts is an unbounded wedge and the
