@@ -815,6 +815,35 @@ def test_cpp_host_layer_unit_tests_and_cli(gpu_ctx, tmp_path):
     assert px[0, 0, 2] >= px[0, 0, 0]
 
 
+def test_two_contexts_interleaved(gpu_ctx):
+    """Two contexts in one process, different scenes and frame sizes, renders interleaved (depth 0, bounce chains
+    with their per-context random streams and tile ordering): each must give what it gives alone."""
+    flat, _ = scenes.default_scene()
+    spec = _random_small_scene(7)
+    a, b = capi.Context(0), capi.Context(0)
+    try:
+        a.upload(flat); b.upload(spec.flatten())
+        cam_a, cam_b = capi.default_viewport(2.0), spec.cam12(1.5)
+        b.set_rng_seed(11)
+        want = {}
+        for rounds in range(2):
+            got = {"a0": a.render(cam_a, 128, 64), "b0": b.render(cam_b, 96, 64),
+                   "a8": a.render(cam_a, 64, 32, spp=121, max_depth=8), "b8": b.render(cam_b, 72, 48, spp=121, max_depth=8),
+                   "a3": a.render(cam_a, 200, 100, max_depth=3)}
+            for k, g in got.items():
+                if rounds == 0:
+                    want[k] = g
+                else:
+                    assert all(np.array_equal(g[x], want[k][x]) for x in ("rgb", "id", "t")), k
+        ora = O.Scene.from_spec(spec); ora.set_rng_seed(11)
+        r = ora.render(cam_b, 72, 48, spp=121, max_depth=8, nthreads=8)
+        assert np.array_equal(want["b8"]["rgb"], r["rgb"]) and np.array_equal(want["b8"]["id"], r["id"])
+        r = O.Scene.default().render(cam_a, 64, 32, spp=121, max_depth=8, nthreads=8)
+        assert np.array_equal(want["a8"]["rgb"], r["rgb"])
+    finally:
+        a.close(); b.close()
+
+
 def test_error_paths(gpu_ctx):
     ctx = capi.Context(0)
     with pytest.raises(capi.MrtError, match="no scene"):
