@@ -815,6 +815,33 @@ def test_cpp_host_layer_unit_tests_and_cli(gpu_ctx, tmp_path):
     assert px[0, 0, 2] >= px[0, 0, 0]
 
 
+def test_device_render_on_a_side_stream_with_counters(gpu_ctx):
+    """mrt_render_device on a stream of the caller's, with the eight device counters (filled by the reduction
+    kernel that follows the render), at depth 0 and in the reference binary's mode."""
+    torch = pytest.importorskip("torch")
+    flat, _ = scenes.default_scene()
+    gpu_ctx.upload(flat)
+    dev = torch.device("cuda:0")
+    side = torch.cuda.Stream(device=dev)
+    for (W, H, spp, depth) in ((320, 200, 1, 0), (96, 48, 121, 8)):
+        cam = capi.default_viewport(W / H)
+        ref = gpu_ctx.render(cam, W, H, spp=spp, max_depth=depth)
+        rgb = torch.zeros((H, W, 3), dtype=torch.float32, device=dev)
+        ids = torch.zeros((H, W), dtype=torch.int32, device=dev)
+        tt = torch.zeros((H, W), dtype=torch.float32, device=dev)
+        st = torch.full((8,), 77, dtype=torch.int64, device=dev)
+        torch.cuda.synchronize()
+        for _ in range(2):   # twice: the counters are rewritten, not accumulated
+            gpu_ctx.render_device(cam, W, H, rgb.data_ptr(), id_ptr=ids.data_ptr(), t_ptr=tt.data_ptr(),
+                                  stats_ptr=st.data_ptr(), stream=side.cuda_stream, spp=spp, max_depth=depth)
+        side.synchronize()
+        assert np.array_equal(rgb.cpu().numpy(), ref["rgb"]) and np.array_equal(ids.cpu().numpy(), ref["id"])
+        assert np.array_equal(tt.cpu().numpy(), ref["t"])
+        s = st.cpu().numpy()
+        assert (int(s[0]), int(s[1]), int(s[2]), int(s[3])) == tuple(ref["stats"][k] for k in
+                                                                     ("primary_rays", "shadow_rays", "hit_pixels", "occluded"))
+
+
 def test_two_contexts_interleaved(gpu_ctx):
     """Two contexts in one process, different scenes and frame sizes, renders interleaved (depth 0, bounce chains
     with their per-context random streams and tile ordering): each must give what it gives alone."""
