@@ -3,30 +3,40 @@
 
     python bench.py --gpus N --steps K --warmup W [--config C2|C3|C4|C5|REF]
 
-A "step" is one frame of the configured workload: every rank renders its strips of the frame
-with the HIP back end (scene already resident in HBM), and for N > 1 the strips are gathered
-to rank 0 over RCCL and assembled.  Default workload = BASELINE.json configs[1]: the
-reference's default scene (src/main.cu:183-237) at 1920x1080, 1 spp, primary + shadow rays.
-REF (not a BASELINE config) is what the reference binary itself renders: the same scene at 2048x1024,
-121 samples per pixel, bounce chains to depth 8 (src/main.cu:26, :165).
+A "step" is one frame of the configured workload: every rank renders its strips of the frame with the HIP back
+end (scene already resident in HBM); for N > 1 every rank but 0 then sends its strips to rank 0 over RCCL (one
+message per peer) and rank 0 puts them in place.  Default workload = BASELINE.json configs[1]: the reference's
+default scene (src/main.cu:183-237) at 1920x1080, 1 spp, primary + shadow rays.  REF (not a BASELINE config) is
+what the reference binary itself renders: the same scene at 2048x1024, 121 samples per pixel, bounce chains to
+depth 8 (src/main.cu:26, :165).
+
+With --gpus N > 1 and no WORLD_SIZE in the environment the script starts its own N ranks
+(python -m torch.distributed.run ... bench.py, as the driver would) before it touches a GPU, relays rank 0's JSON
+line and exits with the children's status.
 
 Prints ONE JSON line on rank 0 (contract in the task statement), including
-  roofline      -- dominant kernel (render_kernel) vs the HBM roof, algorithmic bytes/launch
-  roofline_valu -- the same launches vs the fp32 vector-ALU roof, algorithmic flops/launch
-  cpu_baseline  -- the CPU oracle ("port") timed on this host, bounded sample (rank 0, N=1 only)
+  roofline      -- the render kernel against the HBM roof: algorithmic bytes per launch / its HIP-event time
+  executed_work -- what the kernel executed per launch according to the committed rocprofv3 counter passes
+                   (profiles/counters.json): vector instructions, their issue time, waves per SIMD, HBM bytes
+  end_to_end    -- blocking mrt_render into page-locked host memory (launch + sync + frame in host memory, which is
+                   what src/main.cu:239-247 does), N = 1 only, outside the headline's timed region
+  cpu_baseline  -- the CPU oracle ("port") timed on this host, bounded sample (rank 0, N = 1 only)
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-VALU_PEAK_TFLOPS = 157.3     # fp32 vector peak (packed FMA); no-FMA packed ceiling is half, plain a quarter
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured with a float4 copy)
+VALU_PEAK_TFLOPS = 157.3     # fp32 vector peak (packed FMA); parity forbids FMA: a quarter of it with plain mul / add
 BYTES_PER_PIXEL = 20         # RGB f32 + id i32 + t f32 (SURVEY 8(d))
+SIMDS = 1024                 # 256 CUs x 4
+VALU_ISSUE_NS = 2.0 / 2.4    # MI355X_MICROARCH.md: a wave64 vector instruction issues over 2 cycles at 2.4 GHz
 
 
 def build_workload(name):
@@ -65,19 +75,14 @@ def build_workload(name):
     return flat, cam12, W, H, flops, scene_bytes, spec, label, spp, max_depth
 
 
-def measured_traffic(config, alg_bytes):
-    """HBM bytes per launch from the committed PMC passes (profiles/hbm_traffic.json, produced by
-    tools/pmc_bench.sh: FETCH_SIZE and WRITE_SIZE in separate rocprofv3 --pmc runs of this command).
-    gfx950 correction from MI355X_MICROARCH.md: FETCH_SIZE counts half the bytes of wide reads -> x2;
-    both counters are in KiB."""
-    path = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+def committed_counters(config, brute):
+    """Per-launch rocprofv3 counters of the render kernel from the committed passes (profiles/counters.json, written
+    by tools/profile_config.sh + tools/summarize_profile.py on the GPU box: SQ counters, FETCH_SIZE and WRITE_SIZE
+    each in a --pmc run of its own of THIS command).  Not measured by this run: the JSON says where they come from."""
     try:
-        with open(path) as f:
-            t = json.load(f).get(config)
-        if not t:
-            return None
-        return int((2.0 * t["FETCH_SIZE_KB"] + t["WRITE_SIZE_KB"]) * 1024)
-    except (OSError, ValueError, KeyError):
+        with open(os.path.join(ROOT, "profiles", "counters.json")) as f:
+            return json.load(f).get(config + ("_brute" if brute else ""))
+    except (OSError, ValueError):
         return None
 
 
@@ -115,6 +120,59 @@ def cpu_baseline(name, spec, flat, cam12, W, H, spp=1, max_depth=0):
     }
 
 
+def end_to_end(fr, cam12, W, H, spp, max_depth, rays_per_frame, frames):
+    """Blocking mrt_render of the whole frame into page-locked host memory (mrt_host_alloc): launch + sync + the
+    frame readable by the host, as src/main.cu:239-247 leaves it.  Includes the 20 B/pixel copy over PCIe."""
+    import numpy as np
+    from raytracing_amd import capi
+
+    hb = capi.HostBuffer(W * H * 20)
+    rgb = hb.view(np.float32, (H, W, 3))
+    ids = hb.view(np.int32, (H, W), offset=W * H * 12)
+    t = hb.view(np.float32, (H, W), offset=W * H * 16)
+    fr.ctx.render_into(cam12, W, H, rgb, ids, t, spp=spp, max_depth=max_depth)  # first call sizes the staging buffer
+    t0 = time.perf_counter()
+    for _ in range(frames):
+        fr.ctx.render_into(cam12, W, H, rgb, ids, t, spp=spp, max_depth=max_depth)
+    ms = (time.perf_counter() - t0) / frames * 1e3
+    del rgb, ids, t
+    hb.free()
+    return {"ms": round(ms, 4), "Mrays/s": round(rays_per_frame / ms / 1e3, 1), "buffer": "page-locked",
+            "frames": frames, "what": "blocking mrt_render: kernel + device-to-host copy of rgb, id and t + sync"}
+
+
+def free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def launch_ranks(n):
+    """bench.py --gpus N called directly: start N ranks the way the driver does, before any GPU call here (a process
+    that has initialised the GPU must not be replaced, and need not be: this parent only relays).  Returns the
+    children's exit status."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr",
+           "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    line = None
+    for ln in proc.stdout.splitlines():
+        if ln.startswith("{") and '"metric"' in ln:
+            line = ln
+    if line is not None:
+        print(line, flush=True)
+    elif proc.stdout:
+        sys.stderr.write(proc.stdout[-4000:])
+    if proc.returncode == 0 and line is None:
+        print("bench.py: the ranks exited cleanly but printed no result line", file=sys.stderr)
+        return 1
+    return proc.returncode
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -122,9 +180,12 @@ def main():
     ap.add_argument("--warmup", type=int, default=None)
     ap.add_argument("--config", default="C2")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-ids", action="store_true", help="write RGB only (12 B/pixel)")
     ap.add_argument("--brute-force", action="store_true", help="use the every-ray-every-primitive kernel")
+    ap.add_argument("--dump-frame", default=None, help="rank 0 saves the last frame (rgb, id, t) to this .npz")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(launch_ranks(args.gpus))
 
     import torch
     import torch.distributed as dist
@@ -134,18 +195,18 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
-        args.gpus = world
+    args.gpus = world
+    backend = os.environ.get("MRT_BENCH_BACKEND", "nccl")  # "gloo": rehearsal on a box with fewer GPUs than ranks
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: there is no CPU fallback of the product path")
-    if os.environ.get("MRT_BENCH_BACKEND", "nccl") != "nccl":
+    if backend != "nccl":
         local_rank = local_rank % torch.cuda.device_count()  # rehearsal: ranks share the GPUs there are
+    elif local_rank >= torch.cuda.device_count():
+        raise SystemExit(f"rank {rank}: {world} ranks over RCCL need {world} GPUs, this node shows "
+                         f"{torch.cuda.device_count()} (MRT_BENCH_BACKEND=gloo rehearses the path on fewer)")
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        backend = os.environ.get("MRT_BENCH_BACKEND", "nccl")  # "gloo": rehearsal on a box with fewer GPUs than ranks
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
         else:
@@ -157,15 +218,14 @@ def main():
 
     progress(f"building workload {args.config}")
     flat, cam12, W, H, flops_ray, scene_bytes, spec, label, spp, max_depth = build_workload(args.config)
-    heavy = args.config in ("C3", "C4")
-    heavy = heavy or args.config == "REF"
+    heavy = args.config in ("C3", "C4", "REF")
     steps = args.steps if args.steps is not None else (3 if args.config == "C4" else (20 if heavy else 500))
     warmup = args.warmup if args.warmup is not None else (1 if heavy else 50)
 
-    fr = multigpu.FrameRenderer(flat, cam12, W, H, rank=rank, num_ranks=world, device=local_rank,
-                                with_ids=not args.no_ids, spp=spp, max_depth=max_depth)
+    fr = multigpu.FrameRenderer(flat, cam12, W, H, rank=rank, num_ranks=world, device=local_rank, spp=spp,
+                                max_depth=max_depth)
     fr.ctx.set_cull(0 if args.brute_force else 1)
-    bytes_pp = 12 if args.no_ids else BYTES_PER_PIXEL
+    bytes_pp = BYTES_PER_PIXEL
     if max_depth > 0:
         bytes_pp += 20  # the pixel's random stream: five xorshift words read per frame (mrt_rng.hip)
 
@@ -188,51 +248,58 @@ def main():
     for _ in range(warmup):
         fr.step()
     sync()
-    # HIP events on the stream the kernel is launched on (torch's current stream).  At N=1 with many steps the
-    # events bracket groups of 8 back-to-back launches (a frame lasts ~20 us; an event pair around a single
-    # launch adds its own microsecond or two) and the group time is divided by 8; otherwise they bracket the
-    # render kernel of every step (the gather/assembly follow the second event).
-    group = 8 if (world == 1 and steps >= 64) else 1
-    ev = {k: (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-          for k in range(0, steps - group + 1, group)}
+    # The timed region: exactly `steps` frames between two barriers + synchronisations, nothing else in it.  At
+    # N = 1 one HIP-event pair on the launch stream (torch's current stream) brackets the whole loop: its time over
+    # `steps` is the kernel's average launch-to-launch duration (no per-step events: a pair costs 2-3 us of a 19 us
+    # frame).  At N > 1 the kernel is timed afterwards, the same way, on render-only frames.
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
-    for k in range(steps):
-        e = ev.get(k - k % group)
-        if e and k % group == 0:
-            e[0].record()
-        fr.render_local()
-        if e and k % group == group - 1:
-            e[1].record()
-        if world > 1:
-            multigpu.gather_strips(fr.rgb, world, rank, dst=0, out=fr.gathered)
-            if rank == 0:
-                fr.ctx.assemble_strips(fr.gathered.data_ptr(), fr.gathered.shape[1], fr.frame.data_ptr(), W, H, 3,
-                                       world, fr.strip_rows, stream=torch.cuda.current_stream().cuda_stream)
+    if world == 1:
+        e0.record()
+        for _ in range(steps):
+            fr.render_local()
+        e1.record()
+    else:
+        for _ in range(steps):
+            fr.step()
     sync()
     elapsed = time.perf_counter() - t0
     el = torch.tensor([elapsed], dtype=torch.float64, device=fr.dev)
     if world > 1:
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
+        ksteps = min(steps, 50)
+        e0.record()
+        for _ in range(ksteps):
+            fr.render_local()
+        e1.record()
+        torch.cuda.synchronize()
+        kern_ms = e0.elapsed_time(e1) / ksteps
+    else:
+        kern_ms = e0.elapsed_time(e1) / steps
     elapsed = float(el.item())
-    kern_ms = sum(a.elapsed_time(b) for a, b in ev.values()) / (len(ev) * group)
+
+    if args.dump_frame and world > 1:
+        fr.step()
+    frame = fr.frame_host() if args.dump_frame else None
+    if rank == 0 and frame is not None:
+        import numpy as np
+        np.savez(args.dump_frame, **frame)
 
     if rank == 0:
         ms_per_step = elapsed / steps * 1e3
         value = rays_per_frame * steps / elapsed / 1e6
-        # dominant kernel = render_kernel; per launch this rank processes its own strips
+        # dominant kernel = the render kernel; per launch this rank processes its own strips
         my_pixels = fr.local_rows * W
         my_rays = mine["primary_rays"] + mine["shadow_rays"]
         alg_bytes = my_pixels * bytes_pp + scene_bytes
-        alg_flops = my_rays * flops_ray
         ach_gbs = alg_bytes / (kern_ms * 1e-3) / 1e9
-        ach_tf = alg_flops / (kern_ms * 1e-3) / 1e12
         small = flat.num_spheres + flat.num_triangles <= 64
         if max_depth > 0:
             kernel_name = "render_bounce_small_kernel" if small else "render_bounce_kernel"
             kernel_desc = ("render_bounce_small_kernel: 8x8-pixel tiles, every lane walks its pixel's samples and bounce "
                            "chains as its own state machine (XORWOW stream per pixel); per-tile candidates for primary "
                            "rays, shadow bundles, brute force further down the chains")
-        elif not fr.ctx.cull:
+        elif args.brute_force:
             kernel_name, kernel_desc = "render_kernel", "render_kernel (brute force: every ray x every primitive)"
         elif small:
             kernel_name = "render_small_kernel"
@@ -242,6 +309,11 @@ def main():
             kernel_name = "render_cull_kernel"
             kernel_desc = ("render_cull_kernel: per-tile conservative culling over the kd-ordered primitive "
                            "hierarchy + exact tests")
+        pmc = committed_counters(args.config, args.brute_force) if world == 1 else None
+        traffic = None
+        if pmc and "FETCH_SIZE_KB" in pmc and "WRITE_SIZE_KB" in pmc:
+            # gfx950 correction (MI355X_MICROARCH.md, HBM): FETCH_SIZE counts half the bytes of wide reads; both in KiB
+            traffic = int((2.0 * pmc["FETCH_SIZE_KB"] + pmc["WRITE_SIZE_KB"]) * 1024)
         out = {
             "metric": "Mrays/s (primary+shadow) at 1920x1080" if args.config in ("C2", "C5") else
                       "Mrays/s (primary+shadow at every level) at 2048x1024, 121 spp, depth 8" if args.config == "REF" else
@@ -251,23 +323,53 @@ def main():
             "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{args.config}: {label}", "width": W, "height": H, "spp": spp, "max_depth": max_depth,
                        "primary_rays": primary, "shadow_rays": shadow,
-                       "parallelism": f"{world} GPU(s): 8-row strips round-robin, scene replicated" +
-                                      ("" if world == 1 else ", RCCL gather to rank 0 + strip assembly"),
-                       "outputs": "rgb f32 + id i32 + t f32" if not args.no_ids else "rgb f32",
+                       "parallelism": f"{world} GPU(s): strips of {fr.strip_rows} rows round-robin, scene replicated" +
+                                      ("" if world == 1 else ", one RCCL message per peer to rank 0 (rgb + id + t), "
+                                                             "rank 0 renders in place and scatters the rest"),
+                       "outputs": "rgb f32 + id i32 + t f32" + ("" if world == 1 else ", all three gathered on rank 0"),
                        "kernel": kernel_desc},
             "roofline": {"bound": "hbm", "achieved": round(ach_gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(ach_gbs / HBM_PEAK_GBS, 5),
-                         "traffic": measured_traffic(args.config, alg_bytes) if world == 1 else None,
+                         "frac": round(ach_gbs / HBM_PEAK_GBS, 5), "traffic": traffic,
+                         "traffic_source": pmc.get("source") if (pmc and traffic is not None) else None,
                          "kernel": kernel_name, "kernel_ms": round(kern_ms, 5),
-                         "algorithmic_bytes_per_launch": alg_bytes},
-            "roofline_valu": {"bound": "fp32 vector ALU (no MFMA: no dense contraction)",
-                              "achieved": round(ach_tf, 4), "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
-                              "frac": round(ach_tf / VALU_PEAK_TFLOPS, 5),
-                              "frac_of_no_fma_packed_ceiling": round(ach_tf / (VALU_PEAK_TFLOPS / 2), 5),
-                              "algorithmic_flops_per_ray": flops_ray, "algorithmic_flops_per_launch": alg_flops},
+                         "kernel_ms_how": f"one HIP-event pair around {steps if world == 1 else min(steps, 50)} "
+                                          "back-to-back launches on the launch stream",
+                         "algorithmic_bytes_per_launch": alg_bytes,
+                         "binding_resource": "vector-instruction issue, not HBM (see executed_work; DESIGN.md 5.5)"},
         }
+        if pmc and "SQ_INSTS_VALU" in pmc:
+            # what the kernel executed, not what a brute-force kernel would have: committed counter passes
+            valu = pmc["SQ_INSTS_VALU"]
+            issue_ms = valu / SIMDS * VALU_ISSUE_NS * 1e-6
+            ex = {"source": pmc.get("source"), "valu_insts_per_launch": int(valu),
+                  "valu_issue_ms": round(issue_ms, 5),
+                  "valu_issue_frac_of_kernel_time": round(issue_ms / kern_ms, 4),
+                  "valu_issue_model": "SQ_INSTS_VALU / 1024 SIMDs x 2 cycles at 2.4 GHz (MI355X_MICROARCH.md)"}
+            if "SQ_WAVES" in pmc:
+                ex["waves_per_launch"] = int(pmc["SQ_WAVES"])
+            if pmc.get("GRBM_GUI_ACTIVE") and pmc.get("SQ_WAVE_CYCLES"):
+                # SQ_WAVE_CYCLES: quad-cycles summed over waves; GRBM_GUI_ACTIVE: busy cycles summed over the 8 XCDs
+                # (MI355X_MICROARCH.md) -> average resident waves per SIMD while the kernel runs
+                ex["avg_waves_per_simd"] = round(4.0 * pmc["SQ_WAVE_CYCLES"] / (pmc["GRBM_GUI_ACTIVE"] / 8.0) / SIMDS, 2)
+            if pmc.get("vgpr"):
+                ex["vgpr"], ex["occupancy_waves_per_simd"] = pmc["vgpr"], pmc.get("occupancy")
+            if pmc.get("SQ_ACTIVE_INST_VALU") and pmc.get("SQ_WAVE_CYCLES"):
+                ex["valu_active_frac_of_wave_cycles"] = round(pmc["SQ_ACTIVE_INST_VALU"] / pmc["SQ_WAVE_CYCLES"], 4)
+            out["executed_work"] = ex
+        if args.brute_force:
+            # only the brute-force kernel executes the algorithmic flop count (23 per sphere test, 36 per triangle test)
+            alg_flops = my_rays * flops_ray
+            ach_tf = alg_flops / (kern_ms * 1e-3) / 1e12
+            out["roofline_valu"] = {"bound": "fp32 vector ALU (no MFMA: no dense contraction)",
+                                    "achieved": round(ach_tf, 4), "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                    "frac": round(ach_tf / VALU_PEAK_TFLOPS, 5),
+                                    "algorithmic_flops_per_ray": flops_ray, "algorithmic_flops_per_launch": alg_flops}
+        if world == 1:
+            progress(f"GPU done ({ms_per_step:.4f} ms/step, kernel {kern_ms:.4f} ms); end-to-end frames")
+            out["end_to_end"] = end_to_end(fr, cam12, W, H, spp, max_depth, rays_per_frame,
+                                           3 if args.config in ("C4", "REF") else 20)
         if world == 1 and not args.no_cpu_baseline:
-            progress(f"GPU done ({ms_per_step:.4f} ms/step); timing the CPU oracle (bounded sample, ~20 s)")
+            progress("timing the CPU oracle (bounded sample, ~20 s)")
             out["cpu_baseline"] = cpu_baseline(args.config, spec, flat, cam12, W, H, spp, max_depth)
         print(json.dumps(out), flush=True)
 

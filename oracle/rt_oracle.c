@@ -804,6 +804,42 @@ int orc_triangle_hit(const float a[3], const float b[3], const float c[3], const
   return emit_hit(triangle_hit(&tr, &ray, I, &h), &h, t, point, normal);
 }
 
+/* object i as it was added: kind, geometry (sphere: centre xyz, radius; triangle: a, b, c; plane: k, normal), material */
+int orc_scene_get_object(const orc_scene *s, int i, int *geom_kind, float geom[9], int *mat_kind, float rgb[3])
+{
+  if (!s || i < 0 || i >= s->nobj) return -1;
+  const object_t *o = &s->obj[i];
+  memset(geom, 0, 9 * sizeof(float));
+  *geom_kind = o->geom_kind;
+  switch (o->geom_kind) {
+  case ORC_GEOM_SPHERE: v3_to(o->g.s.c, geom); geom[3] = o->g.s.r; break;
+  case ORC_GEOM_TRIANGLE: v3_to(o->g.t.a, geom); v3_to(o->g.t.b, geom + 3); v3_to(o->g.t.c, geom + 6); break;
+  default: geom[0] = o->g.p.k; v3_to(o->g.p.n, geom + 1); break;
+  }
+  *mat_kind = o->mat_kind;
+  v3_to(o->color, rgb);
+  return 0;
+}
+
+/* core/sphere.cuh:26-30 (compute_quadratic_params :89-114): strictly positive discriminant */
+int orc_sphere_can_hit(const float c[3], float r, const float ro[3], const float rd[3])
+{
+  v3 o = v3_from(ro), d = v3_from(rd);
+  v3 oc = v3_sub(o, v3_from(c));
+  float a = v3_dot(d, d);
+  float b = v3_dot(oc, d);
+  float cc = v3_dot(oc, oc) - r * r;
+  float disc = b * b - a * cc;
+  return disc > 0.0f;
+}
+
+/* core/triangle.cuh:68-75: the ray is not parallel to the triangle's plane */
+int orc_triangle_can_hit(const float a[3], const float b[3], const float c[3], const float rd[3])
+{
+  triangle_t tr = triangle_make(v3_from(a), v3_from(b), v3_from(c));
+  return v3_dot(v3_from(rd), tr.pn) != 0.0f;
+}
+
 int orc_triangle16_hit(const float q[16], const float ro[3], const float rd[3], float tmin, float tmax, float *t,
                        float point[3], float normal[3])
 {

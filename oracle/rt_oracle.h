@@ -90,6 +90,10 @@ int orc_sphere_hit(const float c[3], float r, const float ro[3], const float rd[
                    float *t, float point[3], float normal[3]);
 int orc_triangle_hit(const float a[3], const float b[3], const float c[3], const float ro[3],
                      const float rd[3], float tmin, float tmax, float *t, float point[3], float normal[3]);
+int orc_scene_get_object(const orc_scene *s, int i, int *geom_kind, float geom[9], int *mat_kind, float rgb[3]);
+/* Sphere::can_hit (core/sphere.cuh:26-30) and Triangle::can_hit (core/triangle.cuh:68-75); unused by render */
+int orc_sphere_can_hit(const float c[3], float r, const float ro[3], const float rd[3]);
+int orc_triangle_can_hit(const float a[3], const float b[3], const float c[3], const float rd[3]);
 int orc_triangle16_hit(const float tri16[16], const float ro[3], const float rd[3], float tmin, float tmax,
                        float *t, float point[3], float normal[3]);
 

@@ -756,7 +756,7 @@ __device__ __forceinline__ void render_bounce_body(const Args &S)
 
   if (valid) { // src/main.cu:155
     const float fn = float(nsamp);
-    const size_t pix = size_t(lrow) * A.W + col;
+    const size_t pix = size_t(A.frame_layout ? grow : lrow) * A.W + col;
     A.rgb[3 * pix + 0] = accr / fn;
     A.rgb[3 * pix + 1] = accg / fn;
     A.rgb[3 * pix + 2] = accb / fn;

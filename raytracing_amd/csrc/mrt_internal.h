@@ -73,6 +73,7 @@ struct RenderArgs {
   int32_t W, H;
   int32_t rank, nranks, strip_rows; // strip partition
   int32_t local_rows;
+  int32_t frame_layout;             // 0: buffers hold the rank's rows back to back; 1: whole frames, rows at their final place
   int32_t spp;                      // 1 or 121
   int32_t max_depth;                // 0: primary + shadow; 1..8: mirror chains (mrt_bounce.hip)
   float *rgb;                       // [local_rows*W*3]
@@ -96,8 +97,6 @@ struct RenderArgs {
 };
 
 hipError_t launch_render_cull(const RenderArgs &args, hipStream_t stream);
-// two-level culling (mrt_cull2.hip); waves = 4 (32x32-pixel super-tiles) or 8 (64x32)
-hipError_t launch_render_cull2(const RenderArgs &args, int waves, hipStream_t stream);
 
 // scenes of at most 64 primitives (mrt_small.hip); needs args.utab / args.vtab
 // host copy of a small scene in device order, from which the launcher derives the camera-dependent kernel arguments
@@ -148,7 +147,15 @@ hipError_t launch_intersect(int prim_kind, const float *prim_dev, const float *r
                             hipStream_t stream);
 hipError_t launch_stats_reduce(const unsigned long long *slots, int nslots, unsigned long long *out8,
                                hipStream_t stream);
-hipError_t launch_assemble(const uint32_t *gathered, size_t rank_stride_elems, uint32_t *frame, int W, int H,
-                           int elem_dwords, int nranks, int strip_rows, hipStream_t stream);
+// rank 0 after the gather (mrt_scatter_strips): packed per-rank buffers -> the three frame planes
+enum { MAX_RANKS = 64 };
+struct ScatterArgs {
+  const uint32_t *staging;
+  uint32_t *rgb, *id, *t;          // frame planes (id / t may be null)
+  int32_t W, H, nranks, strip_rows, skip_rank;
+  int32_t rank_rows[MAX_RANKS];    // rows of rank r
+  uint64_t rank_off[MAX_RANKS];    // dword offset of rank r's packed buffer in staging
+};
+hipError_t launch_scatter(const ScatterArgs &S, hipStream_t stream);
 
 } // namespace mrt

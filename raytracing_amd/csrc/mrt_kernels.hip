@@ -589,7 +589,7 @@ __global__ __launch_bounds__(256) void render_kernel(RenderArgs A)
 #pragma unroll
   for (int p = 0; p < P; ++p) {
     if (valid[p]) {
-      const size_t pix = size_t(lrow) * A.W + (col0 + p);
+      const size_t pix = size_t(A.frame_layout ? grow : lrow) * A.W + (col0 + p);
       A.rgb[3 * pix + 0] = accr[p] / fn;
       A.rgb[3 * pix + 1] = accg[p] / fn;
       A.rgb[3 * pix + 2] = accb[p] / fn;
@@ -634,7 +634,12 @@ hipError_t launch_render(const RenderArgs &in, hipStream_t stream)
     A.t_cap = 256;  // 16 KiB triangle records + 1 KiB numerators
   }
   const size_t lds = lds_bytes(A.s_cap, A.t_cap);
-  static const int forced_p = [] { const char *e = getenv("MRT_PIXELS_PER_LANE"); return e ? atoi(e) : 0; }();
+  // only 1, 2 and 4 are instantiated; anything else keeps the default (the grid is sized from the P that runs)
+  static const int forced_p = [] {
+    const char *e = getenv("MRT_PIXELS_PER_LANE");
+    const int x = e ? atoi(e) : 0;
+    return (x == 1 || x == 2 || x == 4) ? x : 0;
+  }();
   const int P = forced_p ? forced_p : 1;
   dim3 grid((A.W + 32 * P - 1) / (32 * P), (A.local_rows + 7) / 8);
   if (grid.x == 0 || grid.y == 0) return hipSuccess;
@@ -707,34 +712,52 @@ hipError_t launch_intersect(int prim_kind, const float *prim_dev, const float *r
 }
 
 // ------------------------------------------------------------------------------------------
-// strip assembly on rank 0 after the gather
+// strip scatter on rank 0 after the gather: every strip of every sending rank is three contiguous blocks (its rows
+// of the rgb, id and t planes) in that rank's packed buffer and three contiguous blocks in the frame buffers.
+// grid = (chunks, strips); a workgroup copies its share of its strip's three blocks, 16 bytes per thread and step
+// where source, destination and size allow it.
 // ------------------------------------------------------------------------------------------
 
-__global__ __launch_bounds__(256) void assemble_kernel(const uint32_t *__restrict__ gathered, size_t rank_stride,
-                                                       uint32_t *__restrict__ frame, int W, int H, int ed, int nranks,
-                                                       int strip_rows)
+__device__ __forceinline__ void copy_block(const uint32_t *__restrict__ src, uint32_t *__restrict__ dst, size_t dwords)
 {
-  const size_t row_dwords = size_t(W) * ed;
-  const size_t total = size_t(H) * row_dwords;
-  for (size_t i = size_t(blockIdx.x) * blockDim.x + threadIdx.x; i < total; i += size_t(gridDim.x) * blockDim.x) {
-    const int row = int(i / row_dwords);
-    const size_t within = i - size_t(row) * row_dwords;
-    const int strip = row / strip_rows;
-    const int r = strip % nranks;
-    const int lrow = (strip / nranks) * strip_rows + (row - strip * strip_rows);
-    frame[i] = gathered[size_t(r) * rank_stride + size_t(lrow) * row_dwords + within];
+  const size_t tid = size_t(blockIdx.x) * blockDim.x + threadIdx.x, nthr = size_t(gridDim.x) * blockDim.x;
+  if ((((uintptr_t)src | (uintptr_t)dst) & 15) == 0) {
+    const size_t n4 = dwords >> 2;
+    const uint4 *s4 = reinterpret_cast<const uint4 *>(src);
+    uint4 *d4 = reinterpret_cast<uint4 *>(dst);
+    for (size_t i = tid; i < n4; i += nthr) d4[i] = s4[i];
+    for (size_t i = (n4 << 2) + tid; i < dwords; i += nthr) dst[i] = src[i];
+  } else {
+    for (size_t i = tid; i < dwords; i += nthr) dst[i] = src[i];
   }
 }
 
-hipError_t launch_assemble(const uint32_t *gathered, size_t rank_stride_elems, uint32_t *frame, int W, int H,
-                           int elem_dwords, int nranks, int strip_rows, hipStream_t stream)
+__global__ __launch_bounds__(256) void scatter_kernel(ScatterArgs S)
 {
-  const size_t total = size_t(W) * H * elem_dwords;
-  if (total == 0) return hipSuccess;
-  unsigned blocks = unsigned((total + 255) / 256);
-  if (blocks > 256u * 32u) blocks = 256u * 32u;
-  hipLaunchKernelGGL(assemble_kernel, dim3(blocks), dim3(256), 0, stream, gathered, rank_stride_elems, frame, W, H,
-                     elem_dwords, nranks, strip_rows);
+  const int strip = blockIdx.y;
+  const int r = strip % S.nranks;
+  if (r == S.skip_rank) return; // rendered in place
+  const int row0 = strip * S.strip_rows;
+  const int rows = row0 + S.strip_rows <= S.H ? S.strip_rows : S.H - row0;
+  const size_t lrow0 = size_t(strip / S.nranks) * S.strip_rows; // the strip's first row in its rank's buffer
+  const size_t W = size_t(S.W), rr = size_t(S.rank_rows[r]);
+  const uint32_t *base = S.staging + S.rank_off[r];
+  copy_block(base + lrow0 * W * 3, S.rgb + size_t(row0) * W * 3, size_t(rows) * W * 3);
+  if (S.id) copy_block(base + rr * W * 3 + lrow0 * W, S.id + size_t(row0) * W, size_t(rows) * W);
+  if (S.t) copy_block(base + rr * W * 4 + lrow0 * W, S.t + size_t(row0) * W, size_t(rows) * W);
+}
+
+hipError_t launch_scatter(const ScatterArgs &S, hipStream_t stream)
+{
+  const int nstrips = (S.H + S.strip_rows - 1) / S.strip_rows;
+  if (nstrips <= 0 || S.W <= 0) return hipSuccess;
+  // enough workgroups per strip to keep about 2048 in flight, at least 4 KB of rgb each
+  const size_t strip_dwords = size_t(S.strip_rows) * S.W * 3;
+  unsigned chunks = unsigned((2048 + nstrips - 1) / nstrips);
+  const unsigned most = unsigned((strip_dwords + 1023) / 1024);
+  if (chunks > most) chunks = most;
+  if (chunks < 1) chunks = 1;
+  hipLaunchKernelGGL(scatter_kernel, dim3(chunks, nstrips), dim3(256), 0, stream, S);
   return hipGetLastError();
 }
 

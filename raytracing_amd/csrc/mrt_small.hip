@@ -481,7 +481,7 @@ __device__ __forceinline__ void render_small_body(const SmallArgs &S)
 #pragma unroll
     for (int p = 0; p < P; ++p) { accr[p] = accr[p] / fn; accg[p] = accg[p] / fn; accb[p] = accb[p] / fn; }
   }
-  const size_t pix0 = size_t(lrow) * A.W + col0;
+  const size_t pix0 = size_t(A.frame_layout ? grow : lrow) * A.W + col0;
   if (A.wide && valid_row && col0 + P <= A.W) {
     // the lane's 3P floats / P ints / P floats are contiguous and 4P-byte aligned (launcher checks W and pointers)
     using VF = typename VecOf<P>::f;

@@ -26,6 +26,12 @@ public:
   const GeometryVariant &geometry() const { return geometry_; }
   const MaterialVariant &material() const { return material_; }
 
+  // scene_object.cuh:29-33
+  bool can_hit(const Ray &r) const
+  {
+    return std::visit([&r](const auto &g) { return g.can_hit(r); }, geometry_);
+  }
+
   void apply_transform(const Transform &t)
   {
     std::visit([&t](auto &g) { g.apply_transform(t); }, geometry_);

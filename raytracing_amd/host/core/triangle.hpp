@@ -8,6 +8,7 @@
 //  - the side test compares a value that is mathematically 0 against -1e-6 (:23).
 // Unlike the reference, a_, b_, c_ are actually stored, so apply_transform works.
 #pragma once
+#include "core/ray.hpp"
 #include "core/transform.hpp"
 #include "math/vec.hpp"
 
@@ -46,6 +47,8 @@ public:
   }
 
   void apply_transform(const Transform &t) { *this = Triangle(t(a_), t(b_), t(c_)); }
+  // triangle.cuh:68-75: the ray is not parallel to the plane.  Not on the render path.
+  bool can_hit(const Ray &ray) const { return ray.direction().dot(plane_normal_) != 0.0f; }
 
   // the 16 floats the GPU consumes, in the stream order of mrt_scene_desc.tri
   void precomputed(float out[16]) const

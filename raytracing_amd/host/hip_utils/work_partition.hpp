@@ -26,7 +26,7 @@ inline WorkPartition make_work_partition(std::size_t work_elements, std::size_t 
 // strips of strip_rows rows dealt round-robin: strip s -> rank s % num_ranks
 inline mrt_partition make_strip_partition(int rank, int num_ranks, int strip_rows = 8)
 {
-  return mrt_partition{rank, num_ranks, strip_rows};
+  return mrt_partition{rank, num_ranks, strip_rows, 0};
 }
 
 } // namespace rt

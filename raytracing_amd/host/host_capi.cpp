@@ -36,6 +36,32 @@ void rth_triangle_precompute(const float *verts, int64_t n, float *streams)
   }
 }
 
+// rt::SceneObject::can_hit over a sphere / a triangle (core/scene_object.cuh:29-33)
+int rth_sphere_can_hit(const float c[3], float r, const float ro[3], const float rd[3])
+{
+  rt::SceneObject o(rt::Sphere(rt::Vec3f(c[0], c[1], c[2]), r), rt::diffuse_white());
+  return o.can_hit(rt::Ray(rt::Vec3f(ro[0], ro[1], ro[2]), rt::Vec3f(rd[0], rd[1], rd[2]))) ? 1 : 0;
+}
+int rth_triangle_can_hit(const float v[9], const float ro[3], const float rd[3])
+{
+  rt::SceneObject o(rt::Triangle(rt::Vec3f(v[0], v[1], v[2]), rt::Vec3f(v[3], v[4], v[5]), rt::Vec3f(v[6], v[7], v[8])),
+                    rt::diffuse_white());
+  return o.can_hit(rt::Ray(rt::Vec3f(ro[0], ro[1], ro[2]), rt::Vec3f(rd[0], rd[1], rd[2]))) ? 1 : 0;
+}
+
+// The default scene with rt::Transform (rotation r [9, row-major], translation t [3]) applied to every object
+// through SceneObject::apply_transform (core/transform.cuh:6-21, sphere.cuh:75-78, triangle.cuh:105-113), flattened
+void *rth_default_scene_transformed_create(const float r[9], const float t[3])
+{
+  auto s = rt::config::make_default_scene();
+  rt::Mat3f m;
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) m.m[i][j] = r[3 * i + j];
+  const rt::Transform tf(m, rt::Vec3f(t[0], t[1], t[2]));
+  for (std::size_t i = 0; i < s.objects.size(); ++i) s.objects[i].apply_transform(tf);
+  return new rt::FlatScene(rt::flatten(rt::make_view(s.objects), rt::make_view(s.lights)));
+}
+
 // rt::DirectionalLight constructor (normalises): dir[3] -> unit dir
 void rth_directional_light_dir(const float dir[3], float out[3])
 {

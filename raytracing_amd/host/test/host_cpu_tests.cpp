@@ -48,6 +48,18 @@ int main()
   obj.apply_transform(tf);
   EXPECT_TRUE(std::get<rt::Sphere>(obj.geometry()).center().x == -4.0f);
 
+  // can_hit (sphere.cuh:26-30, triangle.cuh:68-75, plane.cuh:20-23, scene_object.cuh:29-33): the reference's
+  // sphere test rays -- a head-on ray can hit, a grazing one (discriminant exactly 0) cannot, although hit() accepts it
+  const rt::Sphere s5(Vec3f{0.0f, 0.0f, -5.0f}, 1.0f);
+  EXPECT_TRUE(s5.can_hit(rt::Ray(Vec3f{0, 0, 0}, Vec3f{0, 0, -1})));
+  EXPECT_TRUE(!s5.can_hit(rt::Ray(Vec3f{-1, 0, 0}, Vec3f{0, 0, -1})));
+  EXPECT_TRUE(!s5.can_hit(rt::Ray(Vec3f{3, 0, 0}, Vec3f{0, 0, -1})));
+  const rt::Triangle tz(Vec3f{0, 1, -1}, Vec3f{-1, -1, -1}, Vec3f{1, -1, -1});
+  EXPECT_TRUE(tz.can_hit(rt::Ray(Vec3f{0, 0, 0}, Vec3f{0, 0, -1})) && !tz.can_hit(rt::Ray(Vec3f{0, 0, 0}, Vec3f{1, 0, 0})));
+  EXPECT_TRUE(!rt::Plane(0.0f, Vec3f{0, 1, 0}).can_hit(rt::Ray(Vec3f{0, 1, 0}, Vec3f{0, -1, 0})));
+  EXPECT_TRUE(rt::SceneObject(tz, rt::diffuse_red()).can_hit(rt::Ray(Vec3f{0, 0, 0}, Vec3f{0, 0.5f, -1})));
+  EXPECT_TRUE(!rt::SceneObject(rt::Plane(0.0f, Vec3f{0, 1, 0}), rt::diffuse_red()).can_hit(rt::Ray(Vec3f{0, 1, 0}, Vec3f{0, -1, 0})));
+
   // Interval: four modes
   EXPECT_TRUE(rt::Interval(0.0f, 1.0f).contains(0.0f) && rt::Interval(0.0f, 1.0f).contains(1.0f));
   EXPECT_TRUE(!rt::Interval(0.0f, 1.0f, false, true).contains(0.0f) && rt::Interval(0.0f, 1.0f, false, true).contains(1.0f));

@@ -47,6 +47,9 @@ def _load():
     lib.orc_triangle_precompute.argtypes = [_f3, _f3, _f3, _f3]
     lib.orc_sphere_hit.argtypes = [_f3, C.c_float, _f3, _f3, C.c_float, C.c_float, _f3, _f3, _f3]
     lib.orc_triangle_hit.argtypes = [_f3, _f3, _f3, _f3, _f3, C.c_float, C.c_float, _f3, _f3, _f3]
+    lib.orc_scene_get_object.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int), _f3, C.POINTER(C.c_int), _f3]
+    lib.orc_sphere_can_hit.argtypes = [_f3, C.c_float, _f3, _f3]
+    lib.orc_triangle_can_hit.argtypes = [_f3, _f3, _f3, _f3]
     lib.orc_triangle16_hit.argtypes = [_f3, _f3, _f3, C.c_float, C.c_float, _f3, _f3, _f3]
     lib.orc_render.argtypes = [C.c_void_p, _f3, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(OrcStats)]
@@ -136,6 +139,16 @@ class Scene:
     def add_point_light(self, p, rgb):
         return lib().orc_add_point_light(self._h, _v(p), _v(rgb))
 
+    def objects(self):
+        """[(geom_kind, geom float32[9], mat_kind, rgb float32[3])] in scene order."""
+        out = []
+        for i in range(self.num_objects):
+            gk, mk = C.c_int(), C.c_int()
+            g, c = (C.c_float * 9)(), (C.c_float * 3)()
+            assert lib().orc_scene_get_object(self._h, i, C.byref(gk), g, C.byref(mk), c) == 0
+            out.append((gk.value, np.array(g[:], np.float32), mk.value, np.array(c[:], np.float32)))
+        return out
+
     def set_rng_seed(self, seed):
         lib().orc_scene_set_rng_seed(self._h, int(seed))
 
@@ -221,3 +234,11 @@ def triangle16_hit(q, ro, rd, tmin, tmax):
     t, p, n = _hit_out()
     ok = lib().orc_triangle16_hit(_v(q), _v(ro), _v(rd), float(tmin), float(tmax), C.byref(t), p, n)
     return (bool(ok), np.float32(t.value), np.array(p[:], np.float32), np.array(n[:], np.float32))
+
+
+def sphere_can_hit(c, r, ro, rd):
+    return bool(lib().orc_sphere_can_hit(_v(c), float(r), _v(ro), _v(rd)))
+
+
+def triangle_can_hit(a, b, c, rd):
+    return bool(lib().orc_triangle_can_hit(_v(a), _v(b), _v(c), _v(rd)))

@@ -20,14 +20,14 @@ GOLD = os.path.join(os.path.dirname(__file__), "golden")
 RGB_TOL = 1.0 / 255.0
 
 
-KERNEL_MODES = {"brute": 0, "cull": 2, "cull2x4": 3, "cull2x8": 4, "small": 5}
+KERNEL_MODES = {"brute": 0, "cull": 2, "small": 5}
 
 
 @pytest.fixture(params=list(KERNEL_MODES), autouse=True)
 def kernel_mode(request, gpu_ctx):
     """Every test runs against every render kernel: brute force (walks every primitive for every ray like
-    the reference loops), one-level tile culling, two-level tile culling with 4 and 8 waves, and the small-scene kernel (which
-    hands scenes of more than 64 primitives to the one-level kernel)."""
+    the reference loops), tile culling over the primitive hierarchy, and the small-scene kernel (which hands scenes
+    of more than 64 primitives to the tile-culling kernel)."""
     gpu_ctx.set_cull(KERNEL_MODES[request.param])
     yield request.param
     gpu_ctx.set_cull(1)
@@ -336,15 +336,86 @@ def test_culling_matches_brute_force_at_full_size(gpu_ctx, kernel_mode, name):
     else:
         spec, (W, H) = scenes.triangle_terrain(200, 100), (1920, 1080)
     gpu_ctx.upload(spec.flatten())
-    brute, one, two4, two8, auto = _render_modes(gpu_ctx, spec.cam12(W / H), W, H, (0, 2, 3, 4, 1))
-    for other, label in ((one, "one-level"), (two4, "two-level x4"), (two8, "two-level x8"), (auto, "automatic")):
+    brute, one, auto = _render_modes(gpu_ctx, spec.cam12(W / H), W, H, (0, 2, 1))
+    for other, label in ((one, "tile culling"), (auto, "automatic")):
         _assert_same(other, brute, f"{name} {label}")
     assert brute["stats"]["hit_pixels"] > 10000
 
 
-def test_dense_cluster_overflows_the_survivor_list(gpu_ctx):
-    """12 000 small spheres and 9 000+ small triangles inside one super-tile: the level-1 survivor list of the
-    two-level kernels (8192 entries) overflows and the pass is redone in spans that fit."""
+_C4 = {}
+
+
+def _c4_scene():
+    """BASELINE.json configs[3]: the 1 000 000-triangle terrain, built once per session (a few seconds of host work)."""
+    if not _C4:
+        spec = scenes.triangle_terrain(1000, 500)
+        flat = spec.flatten()
+        assert flat.num_triangles == 1_000_000
+        # the size-dependent structure DESIGN.md 5.2 describes must really be there: more than one super-cluster
+        # level (15 625 clusters in 245 super-clusters) and triangles the culling can never skip
+        ncl = (flat.num_triangles + 63) // 64
+        assert ncl == 15625 and (ncl + 63) // 64 == 245
+        tri = flat.tri.reshape(16, -1)
+        rng = np.random.default_rng(4)
+        pick = rng.choice(flat.num_triangles, 100000, replace=False)
+        unbounded = sum(1 for i in pick if not np.isfinite(capi.triangle_bound(tri[:, i])[3]))
+        _C4.update(spec=spec, flat=flat, unbounded_in_sample=unbounded)
+    return _C4
+
+
+def test_c4_million_triangles_reduced_frame_vs_oracle(gpu_ctx, kernel_mode):
+    """Config 4 at its real scene size (1M triangles; triangle.cuh:77-103 semantics) on a frame the brute-force
+    oracle finishes: id / t / RGB bit for bit and the ray statistics, under tile culling and under brute force."""
+    if kernel_mode == "small":
+        pytest.skip("more than 64 primitives: same kernel as 'cull'")
+    c4 = _c4_scene()
+    gpu_ctx.upload(c4["flat"])
+    W, H = 160, 90
+    cam = c4["spec"].cam12(W / H)
+    g = gpu_ctx.render(cam, W, H)
+    if "oracle" not in c4:   # 1.4e10 triangle tests: about 20 s on 16 host threads, once for both kernels
+        c4["oracle"] = O.Scene.from_spec(c4["spec"]).render(cam, W, H, nthreads=16)
+    r = c4["oracle"]
+    assert_frame_parity(g, r, "C4 1M triangles 160x90")
+    assert_stats_parity(g["stats"], r["stats"])
+    assert g["stats"]["hit_pixels"] > W * H // 3
+
+
+def test_c4_million_triangles_4k_culling_matches_brute_force(gpu_ctx, kernel_mode):
+    """Config 4 at its real size, 3840x2160: the culled kernel (the bench path) against the every-ray-every-triangle
+    kernel, bit for bit.  The brute-force frame is 8.3e12 triangle tests, several seconds of GPU: it is rendered as
+    the 16 parts of a 16-rank strip partition so that no single kernel runs for long."""
+    if kernel_mode != "cull":
+        pytest.skip("compares the kernels itself")
+    c4 = _c4_scene()
+    assert c4["unbounded_in_sample"] > 0, "no unbounded triangle in a 10 % sample: the scene generator changed"
+    gpu_ctx.upload(c4["flat"])
+    W, H = 3840, 2160
+    cam = c4["spec"].cam12(W / H)
+    one, auto = _render_modes(gpu_ctx, cam, W, H, (2, 1))
+    brute = {"rgb": np.zeros((H, W, 3), np.float32), "id": np.zeros((H, W), np.int32), "t": np.zeros((H, W), np.float32),
+             "stats": {k: 0 for k in ("primary_rays", "shadow_rays", "hit_pixels", "occluded")}}
+    gpu_ctx.set_cull(0)
+    try:
+        for rank in range(16):
+            part = gpu_ctx.render(cam, W, H, rank=rank, num_ranks=16)
+            rows = capi.local_row_index(H, rank, 16)
+            for k in ("rgb", "id", "t"):
+                brute[k][rows] = part[k]
+            for k in brute["stats"]:
+                brute["stats"][k] += part["stats"][k]
+    finally:
+        gpu_ctx.set_cull(1)
+    for other, label in ((one, "tile culling"), (auto, "automatic")):
+        _assert_same(other, brute, f"C4 4K {label}")
+    assert brute["stats"]["hit_pixels"] > W * H // 2
+    # culling did its job: a small fraction of the 8.3 M x 1 M brute-force tests
+    assert 0 < one["stats"]["exact_tests"] < 10 ** 9
+
+
+def test_dense_cluster_inside_a_few_tiles(gpu_ctx):
+    """12 000 small spheres and 9 000+ small triangles inside a few tiles: every cluster of the hierarchy is opened by
+    the same waves."""
     sp = scenes.random_spheres(12000, seed=7, box=((-0.6, 0.6), (-0.4, 0.4), (-26.0, -22.0)), radii=(0.004, 0.012))
     tv = scenes.terrain_triangles(96, 48, x_range=(-0.6, 0.6), z_range=(-26.0, -22.0), amp=0.05, y0=-0.45)
     n = len(sp) + len(tv)
@@ -746,30 +817,76 @@ def test_strip_partition_reassembles_bitwise(gpu_ctx, nranks, strip):
         assert tot[k] == full["stats"][k]
 
 
-def test_device_render_and_strip_assembly(gpu_ctx):
-    """mrt_render_device + mrt_assemble_strips with torch-owned HBM buffers (the bench path)."""
+@pytest.mark.parametrize("W,H,nranks,strip", [(320, 200, 4, 8), (250, 130, 3, 16), (96, 52, 8, 8)])
+def test_device_render_frame_layout_and_strip_scatter(gpu_ctx, W, H, nranks, strip):
+    """The N > 1 bench path on one GPU: rank 0 renders its strips in place (frame_layout 1), every other rank into a
+    packed rgb | id | t buffer; mrt_scatter_strips puts those strips in place.  Frame == the 1-GPU frame, bitwise."""
     torch = pytest.importorskip("torch")
+    from raytracing_amd import multigpu
     flat, _ = scenes.default_scene()
     gpu_ctx.upload(flat)
-    W, H, nranks = 320, 200, 4
     cam = capi.default_viewport(W / H)
     full = gpu_ctx.render(cam, W, H)
     dev = torch.device("cuda:0")
-    max_rows = capi.local_rows(H, 0, nranks)
-    gathered = torch.zeros((nranks, max_rows * W * 3), dtype=torch.float32, device=dev)
-    gathered_id = torch.full((nranks, max_rows * W), -7, dtype=torch.int32, device=dev)
+    n = W * H
+    frame = torch.full((n * 5,), -3.0, dtype=torch.float32, device=dev)
+    rgb, ids, tt = frame[:n * 3], frame[n * 3:n * 4].view(torch.int32), frame[n * 4:]
+    offsets, total = multigpu.staging_offsets(H, W, nranks, strip, skip_rank=0)
+    staging = torch.zeros(total, dtype=torch.float32, device=dev)
     stream = torch.cuda.current_stream().cuda_stream
-    for rank in range(nranks):
-        gpu_ctx.render_device(cam, W, H, gathered[rank].data_ptr(), id_ptr=gathered_id[rank].data_ptr(), stream=stream,
-                              rank=rank, num_ranks=nranks)
-    frame = torch.zeros((H, W, 3), dtype=torch.float32, device=dev)
-    frame_id = torch.zeros((H, W), dtype=torch.int32, device=dev)
-    gpu_ctx.assemble_strips(gathered.data_ptr(), gathered.shape[1], frame.data_ptr(), W, H, 3, nranks, stream=stream)
-    gpu_ctx.assemble_strips(gathered_id.data_ptr(), gathered_id.shape[1], frame_id.data_ptr(), W, H, 1, nranks,
-                            stream=stream)
+    gpu_ctx.render_device(cam, W, H, rgb.data_ptr(), id_ptr=ids.data_ptr(), t_ptr=tt.data_ptr(), stream=stream,
+                          rank=0, num_ranks=nranks, strip_rows=strip, frame_layout=1)
+    for rank in range(1, nranks):
+        o, ln = offsets[rank]
+        rows = capi.local_rows(H, rank, nranks, strip)
+        assert ln == rows * W * 5
+        if rows == 0:
+            continue
+        gpu_ctx.render_device(cam, W, H, staging[o:].data_ptr(), id_ptr=staging[o + rows * W * 3:].data_ptr(),
+                              t_ptr=staging[o + rows * W * 4:].data_ptr(), stream=stream, rank=rank, num_ranks=nranks,
+                              strip_rows=strip)
+    gpu_ctx.scatter_strips(staging.data_ptr(), rgb.data_ptr(), ids.data_ptr(), tt.data_ptr(), W, H, nranks, strip,
+                           skip_rank=0, stream=stream)
     torch.cuda.synchronize()
-    assert np.array_equal(frame.cpu().numpy(), full["rgb"])
-    assert np.array_equal(frame_id.cpu().numpy(), full["id"])
+    assert np.array_equal(rgb.view(H, W, 3).cpu().numpy(), full["rgb"])
+    assert np.array_equal(ids.view(H, W).cpu().numpy(), full["id"])
+    assert np.array_equal(tt.view(H, W).cpu().numpy(), full["t"])
+    # the numpy mirror the CPU tests of the N > 1 path use must agree with the kernel
+    h = {"rgb": np.zeros((H, W, 3), np.float32), "id": np.zeros((H, W), np.int32), "t": np.zeros((H, W), np.float32)}
+    rows0 = capi.local_row_index(H, 0, nranks, strip)
+    for k in h:
+        h[k][rows0] = full[k][rows0]
+    multigpu.scatter_strips_host(staging.cpu().numpy(), offsets, h["rgb"], h["id"], h["t"], nranks, strip, skip_rank=0)
+    assert all(np.array_equal(h[k], full[k]) for k in h)
+
+
+def test_frame_layout_under_every_kernel_and_bounces(gpu_ctx):
+    """frame_layout 1 writes a rank's rows at their final places, under every render kernel and the bounce kernel;
+    the rows of other ranks are not touched."""
+    torch = pytest.importorskip("torch")
+    dev = torch.device("cuda:0")
+    W, H, nranks = 136, 52, 3
+    cases = [("default", scenes.default_scene()[0], capi.default_viewport(W / H), 0),
+             ("default d2", scenes.default_scene()[0], capi.default_viewport(W / H), 2)]
+    big = scenes.sphere_field(300)
+    cases.append(("300 spheres", big.flatten(), big.cam12(W / H), 0))
+    for name, flat, cam, depth in cases:
+        gpu_ctx.upload(flat)
+        full = gpu_ctx.render(cam, W, H, max_depth=depth)
+        for rank in range(nranks):
+            rgb = torch.full((H, W, 3), -5.0, dtype=torch.float32, device=dev)
+            ids = torch.full((H, W), -5, dtype=torch.int32, device=dev)
+            tt = torch.full((H, W), -5.0, dtype=torch.float32, device=dev)
+            gpu_ctx.render_device(cam, W, H, rgb.data_ptr(), id_ptr=ids.data_ptr(), t_ptr=tt.data_ptr(),
+                                  stream=torch.cuda.current_stream().cuda_stream, max_depth=depth, rank=rank,
+                                  num_ranks=nranks, frame_layout=1)
+            torch.cuda.synchronize()
+            mine = np.zeros(H, bool)
+            mine[capi.local_row_index(H, rank, nranks)] = True
+            for got, want, k in ((rgb, full["rgb"], "rgb"), (ids, full["id"], "id"), (tt, full["t"], "t")):
+                got = got.cpu().numpy()
+                assert np.array_equal(got[mine], want[mine]), (name, rank, k)
+                assert (got[~mine] == -5).all(), (name, rank, k, "rows of other ranks were written")
 
 
 def test_render_into_page_locked_host_memory(gpu_ctx):
@@ -840,6 +957,138 @@ def test_device_render_on_a_side_stream_with_counters(gpu_ctx):
         s = st.cpu().numpy()
         assert (int(s[0]), int(s[1]), int(s[2]), int(s[3])) == tuple(ref["stats"][k] for k in
                                                                      ("primary_rays", "shadow_rays", "hit_pixels", "occluded"))
+
+
+def test_two_renders_in_flight_on_one_context(gpu_ctx):
+    """Two mrt_render_device calls of ONE context on two streams of the caller's, neither waited for: the context's
+    counters and scratch are shared, so the library orders the second render behind the first on the GPU
+    (include/mrt.h, conventions).  Both frames and both sets of counters must come out as they do alone -- at depth 0
+    and with bounce chains (tile order scratch, random streams)."""
+    torch = pytest.importorskip("torch")
+    flat, _ = scenes.default_scene()
+    gpu_ctx.upload(flat)
+    dev = torch.device("cuda:0")
+    s1, s2 = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
+    jobs = [(640, 360, 1, 0), (320, 200, 1, 0), (96, 48, 121, 4), (128, 64, 121, 2)]
+    want = {j: gpu_ctx.render(capi.default_viewport(j[0] / j[1]), j[0], j[1], spp=j[2], max_depth=j[3]) for j in jobs}
+    for a, b in ((jobs[0], jobs[1]), (jobs[2], jobs[3]), (jobs[0], jobs[2])):
+        bufs = []
+        torch.cuda.synchronize()
+        for rounds in range(3):     # back to back, alternating streams, nothing waited for in between
+            for (W, H, spp, depth), st in ((a, s1), (b, s2)):
+                rgb = torch.zeros((H, W, 3), dtype=torch.float32, device=dev)
+                ids = torch.zeros((H, W), dtype=torch.int32, device=dev)
+                cnt = torch.zeros(8, dtype=torch.int64, device=dev)
+                gpu_ctx.render_device(capi.default_viewport(W / H), W, H, rgb.data_ptr(), id_ptr=ids.data_ptr(),
+                                      stats_ptr=cnt.data_ptr(), stream=st.cuda_stream, spp=spp, max_depth=depth)
+                bufs.append(((W, H, spp, depth), rgb, ids, cnt))
+        torch.cuda.synchronize()
+        for j, rgb, ids, cnt in bufs:
+            assert np.array_equal(rgb.cpu().numpy(), want[j]["rgb"]), j
+            assert np.array_equal(ids.cpu().numpy(), want[j]["id"]), j
+            c = cnt.cpu().numpy()
+            assert (int(c[0]), int(c[1]), int(c[2]), int(c[3])) == tuple(
+                want[j]["stats"][k] for k in ("primary_rays", "shadow_rays", "hit_pixels", "occluded")), j
+
+
+def test_failed_upload_leaves_no_scene(gpu_ctx):
+    """an mrt_scene_upload that fails after the old scene was given up must leave the context without a
+    scene (MRT_ERR_NO_SCENE on the next render), not with dangling device pointers; a later upload recovers."""
+    ctx = capi.Context(0)
+    try:
+        flat, _ = scenes.default_scene()
+        ctx.upload(flat)
+        cam = capi.default_viewport(2.0)
+        good = ctx.render(cam, 64, 32)
+        ctx.fail_next_upload()
+        with pytest.raises(capi.MrtError, match="injected"):
+            ctx.upload(scenes.sphere_field(500).flatten())
+        with pytest.raises(capi.MrtError, match="no scene"):
+            ctx.render(cam, 64, 32)
+        with pytest.raises(capi.MrtError, match="no scene"):
+            ctx.render(cam, 64, 32, max_depth=3)
+        ctx.upload(flat)   # the hook fires once
+        again = ctx.render(cam, 64, 32)
+        assert all(np.array_equal(again[k], good[k]) for k in ("rgb", "id", "t"))
+    finally:
+        ctx.close()
+
+
+def _transform_f32(R, t, v):
+    """rt::Transform::operator() (core/transform.cuh:14-17): r_ * v + t_ in fp32, each coefficient of the product
+    a length-3 sum in the order of DESIGN.md's arithmetic contract."""
+    R, t, v = np.asarray(R, np.float32), np.asarray(t, np.float32), np.asarray(v, np.float32)
+    return np.array([np.float32(np.float32(R[i, 0] * v[0]) + np.float32(np.float32(R[i, 1] * v[1]) + np.float32(R[i, 2] * v[2])))
+                     + t[i] for i in range(3)], np.float32)
+
+
+@pytest.mark.parametrize("case", ["rotate_y_translate", "shear_scale"])
+def test_transformed_scene_through_the_host_layer(gpu_ctx, case):
+    """SURVEY 8(f).4: rt::Transform applied on the host to every object of the default scene
+    (SceneObject::apply_transform: transform.cuh:6-21, sphere.cuh:75-78, triangle.cuh:105-113 -- with a_, b_, c_
+    actually stored), flattened, uploaded and rendered; against the oracle built from the transformed vertices."""
+    if case == "rotate_y_translate":
+        a = np.float32(0.35)
+        R = np.array([[np.cos(a), 0, np.sin(a)], [0, 1, 0], [-np.sin(a), 0, np.cos(a)]], np.float32)
+        t = np.array([0.75, -0.25, -1.5], np.float32)
+    else:
+        R = np.array([[1.1, 0.2, 0.0], [0.0, 0.9, 0.1], [0.05, 0.0, 1.2]], np.float32)
+        t = np.array([-0.5, 0.3, 2.0], np.float32)
+    flat = capi.FlatScene.default(R, t)
+    gpu_ctx.upload(flat)
+    ora = O.Scene()
+    for gk, g, mk, rgb in O.Scene.default().objects():
+        if gk == O.GEOM_SPHERE:
+            ora.add_sphere(_transform_f32(R, t, g[:3]), g[3], mk, rgb)
+        else:
+            assert gk == O.GEOM_TRIANGLE
+            ora.add_triangle(*(_transform_f32(R, t, g[3 * k:3 * k + 3]) for k in range(3)), mk, rgb)
+    ora.add_directional_light(scenes.DEFAULT_LIGHT_DIR, scenes.DEFAULT_LIGHT_RGB)
+    W, H = 320, 160
+    cam = capi.default_viewport(W / H)
+    g = gpu_ctx.render(cam, W, H)
+    r = ora.render(cam, W, H, nthreads=4)
+    assert_frame_parity(g, r, f"transformed default scene ({case})")
+    assert_stats_parity(g["stats"], r["stats"])
+    plain = O.Scene.default().render(cam, W, H, nthreads=4)
+    assert (plain["id"] != r["id"]).sum() > 1000     # the transform really moved things
+    assert (r["id"] >= 0).sum() > 2000
+
+
+def test_can_hit_against_the_gpu_hit_flags(gpu_ctx):
+    """Sphere::can_hit (sphere.cuh:26-30) and Triangle::can_hit (triangle.cuh:68-75) of the host layer against the
+    oracle's restatement, and against mrt_intersect on the reference's known-answer rays and random ones:
+    can_hit is necessary for a hit except for tangent rays (discriminant exactly 0, which hit() accepts), and
+    sufficient for a sphere hit over the unbounded interval."""
+    lo, hi = KA["interval"]
+    for c in KA["sphere"]:
+        ch = capi.sphere_can_hit(c["center"], c["radius"], c["origin"], c["dir"])
+        assert ch == O.sphere_can_hit(c["center"], c["radius"], c["origin"], c["dir"])
+        hit = gpu_ctx.intersect(capi.GEOM_SPHERE, c["center"] + [c["radius"]], np.float32([c["origin"] + c["dir"]]), lo, hi)[0]
+        assert hit[0]
+        tangent = c["name"].endswith(("Left", "Right", "Up", "Down"))   # grazing rays: discriminant exactly 0
+        assert ch != tangent, c["name"]
+    for c in KA["triangle"]:
+        v = [c["a"], c["b"], c["c"]]
+        ch = capi.triangle_can_hit(v, c["origin"], c["dir"])
+        assert ch == O.triangle_can_hit(c["a"], c["b"], c["c"], c["dir"]) and ch
+    rays = _random_rays(600, 11)
+    cs, rs = (0.5, -0.25, -1.0), 1.5
+    hit = gpu_ctx.intersect(capi.GEOM_SPHERE, list(cs) + [rs], rays, -np.inf, np.inf)[0]
+    tv = [(-2.0, -1.5, -1.0), (2.5, -1.0, 0.5), (0.0, 2.0, -0.5)]
+    thit = gpu_ctx.intersect(capi.GEOM_TRIANGLE, capi.triangle_precompute(np.float32([tv]))[:, 0], rays, -np.inf, np.inf)[0]
+    n_can = 0
+    for i, ray in enumerate(rays):
+        ch = capi.sphere_can_hit(cs, rs, ray[:3], ray[3:])
+        assert ch == O.sphere_can_hit(cs, rs, ray[:3], ray[3:])
+        assert (not ch) or hit[i]
+        n_can += ch
+        tch = capi.triangle_can_hit(tv, ray[:3], ray[3:])
+        assert tch == O.triangle_can_hit(*tv, ray[3:])
+        assert tch or not thit[i]
+    assert 0 < n_can < len(rays)
+    flat_tri = [(0, 1, -1), (-1, -1, -1), (1, -1, -1)]     # in the plane z = -1: a ray along x is parallel to it
+    assert not capi.triangle_can_hit(flat_tri, (0, 0, 0), (1, 0, 0)) and not O.triangle_can_hit(*flat_tri, (1, 0, 0))
 
 
 def test_two_contexts_interleaved(gpu_ctx):
