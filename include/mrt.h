@@ -14,7 +14,12 @@
  *  - one context drives ONE GPU (one process per GPU; multi-GPU frames are split
  *    in strips by the caller, see mrt_partition);
  *  - calls on one context are serialised by the caller (the reference is single
- *    threaded, src/main.cu:159-260);
+ *    threaded, src/main.cu:159-260).  Renders of one context share its counters and
+ *    scratch, so the library orders them on the GPU: a render enqueued on another
+ *    stream than the previous one first waits (on the GPU, not the host) for that
+ *    one.  Renders of DIFFERENT contexts overlap freely.  mrt_scene_upload and
+ *    mrt_ctx_destroy wait for the context's own stream and for the stream of its
+ *    last render; work the caller enqueued elsewhere is the caller's to synchronise;
  *  - all arithmetic is fp32 with FMA contraction off and IEEE div/sqrt, in the
  *    operation order documented in DESIGN.md, so hit/ID buffers are bit-comparable
  *    with the CPU oracle.
@@ -89,12 +94,15 @@ typedef struct mrt_camera {
  * Strip partition of a frame over ranks (no reference counterpart: the reference is
  * single GPU).  Rows are dealt in strips of strip_rows rows,
  * strip s -> rank s % num_ranks.  A rank's local buffer holds its strips back to
- * back in ascending order.  {0,1,8} renders the whole frame.
+ * back in ascending order (frame_layout 0).  {0,1,8,0} renders the whole frame.
  */
 typedef struct mrt_partition {
   int32_t rank;
   int32_t num_ranks;
-  int32_t strip_rows; /* multiple of 8 */
+  int32_t strip_rows;   /* multiple of 8 */
+  int32_t frame_layout; /* 0: the buffers hold the rank's rows back to back (local_rows x W);
+                           1: the buffers are whole H x W frames and the rank writes only its own rows, each at its
+                              final place (rank 0 of a multi-GPU frame renders like this and receives the rest) */
 } mrt_partition;
 
 typedef struct mrt_render_params {
@@ -128,13 +136,14 @@ const char *mrt_status_string(int status);
 /*
  * Context options.  MRT_OPT_CULL (no reference counterpart; default 1, or environment MRT_CULL) picks the
  * render kernel: 0 = brute force, which like the reference loops (src/main.cu:67-77) tests every ray against
- * every primitive; 1 = automatic; 2 = one-level tile culling; 3 / 4 = two-level tile culling with 4 / 8 waves
- * per workgroup; 5 = the small-scene kernel (at most 64 primitives, else 2).  All kernels produce identical
- * buffers.  MRT_OPT_RNG_SEED (default 1984, the constant of cuda_utils/curand_state.cuh:22; 0..2^31-1) seeds
- * the per-pixel random streams of diffuse bounces: pixel i of the full frame owns subsequence i, like
- * curand_init(seed, i, 0, ...).
+ * every primitive; 1 = automatic; 2 = tile culling over the primitive hierarchy; 5 = the small-scene kernel (at
+ * most 64 primitives, else 2).  All kernels produce identical buffers.  MRT_OPT_RNG_SEED (default 1984, the
+ * constant of cuda_utils/curand_state.cuh:22; 0..2^31-1) seeds the per-pixel random streams of diffuse bounces:
+ * pixel i of the full frame owns subsequence i, like curand_init(seed, i, 0, ...).
+ * MRT_OPT_FAIL_NEXT_UPLOAD (test hook; value 1) makes the next mrt_scene_upload of the context fail at its
+ * device allocation, after the old scene has been given up: the context must then report MRT_ERR_NO_SCENE.
  */
-enum { MRT_OPT_CULL = 1, MRT_OPT_RNG_SEED = 2 };
+enum { MRT_OPT_CULL = 1, MRT_OPT_RNG_SEED = 2, MRT_OPT_FAIL_NEXT_UPLOAD = 3 };
 int mrt_ctx_set_option(mrt_ctx *ctx, int option, int value);
 
 /*
@@ -171,7 +180,7 @@ int mrt_local_rows(int32_t height, const mrt_partition *part, int32_t *rows);
  * (container/alloc.cuh:13-106).  Buffers hold the rank's local rows:
  * rgb [rows*W*3] linear float RGB, row 0 = v 0 (the reference's pre-flip order);
  * id [rows*W] object number or -1; t [rows*W] closest-hit parameter or +inf.
- * id/t/stats may be NULL.
+ * id/t/stats may be NULL.  params->part.frame_layout must be 0 here.
  */
 int mrt_render(mrt_ctx *ctx, const mrt_camera *cam, const mrt_render_params *params, float *rgb, int32_t *id,
                float *t, mrt_stats *stats);
@@ -179,21 +188,26 @@ int mrt_render(mrt_ctx *ctx, const mrt_camera *cam, const mrt_render_params *par
 /*
  * Asynchronous render into DEVICE buffers on a caller-supplied HIP stream
  * (hipStream_t passed as void*; NULL = HIP's default stream, as in HIP itself).  Same layout
- * as mrt_render.  stats_dev, if not NULL, points to 8 device uint64 that receive
- * primary/shadow/hit/occluded counts, exact-test and opened-cluster counts (2 spare), written by a small kernel
- * that follows the render on the same stream.  The caller synchronises.
+ * as mrt_render, or whole frames with params->part.frame_layout = 1.  stats_dev, if not NULL, points
+ * to 8 device uint64 that receive primary/shadow/hit/occluded counts, exact-test and opened-cluster counts
+ * (2 spare), written by a small kernel that follows the render on the same stream.  The caller synchronises.
+ * The first render of a new frame size (small-scene kernel) or of a larger frame (bounce chains) allocates
+ * device memory; no call synchronises the device.
  */
 int mrt_render_device(mrt_ctx *ctx, const mrt_camera *cam, const mrt_render_params *params, void *rgb_dev,
                       void *id_dev, void *t_dev, void *stats_dev, void *stream);
 
 /*
- * Rank 0, after the gather: scatter the ranks' strip buffers (rank r's buffer at
- * gathered + r*rank_stride elements... see DESIGN.md) into one row-major frame.
- * elem_floats = 3 for rgb, 1 for id/t (4-byte elements).  Device pointers.
+ * Rank 0 of a multi-GPU frame, after the gather (no reference counterpart: SURVEY 8(e)).  Rank 0 has rendered
+ * its own strips in place (frame_layout 1); every other rank r sent ONE packed buffer holding its local rows
+ * back to back as three planes, rgb [rows_r*W*3] | id [rows_r*W] | t [rows_r*W] (4-byte elements, rows_r =
+ * mrt_local_rows), and staging_dev holds those buffers in rank order, rank skip_rank left out (-1: none is).
+ * The call copies every strip of those ranks to its final place in the three H x W frame buffers (frame_id_dev
+ * / frame_t_dev may be NULL).  Device pointers; asynchronous on `stream`.  At most 64 ranks.
  */
-int mrt_assemble_strips(mrt_ctx *ctx, const void *gathered_dev, size_t rank_stride_elems, void *frame_dev,
-                        int32_t width, int32_t height, int32_t elem_dwords, int32_t num_ranks, int32_t strip_rows,
-                        void *stream);
+int mrt_scatter_strips(mrt_ctx *ctx, const void *staging_dev, void *frame_rgb_dev, void *frame_id_dev,
+                       void *frame_t_dev, int32_t width, int32_t height, int32_t num_ranks, int32_t strip_rows,
+                       int32_t skip_rank, void *stream);
 
 /*
  * Batched single-primitive intersection on the GPU: replaces the test kernels

@@ -19,7 +19,7 @@ LIGHT_DIRECTIONAL, LIGHT_POINT = 0, 1
 # every symbol include/mrt.h declares (tests check the library exports all of them)
 MRT_SYMBOLS = [
     "mrt_device_count", "mrt_ctx_create", "mrt_ctx_destroy", "mrt_ctx_set_option", "mrt_last_error", "mrt_status_string",
-    "mrt_triangle_bound", "mrt_rng_state", "mrt_host_alloc", "mrt_host_free", "mrt_scene_upload", "mrt_local_rows", "mrt_render", "mrt_render_device", "mrt_assemble_strips",
+    "mrt_triangle_bound", "mrt_rng_state", "mrt_host_alloc", "mrt_host_free", "mrt_scene_upload", "mrt_local_rows", "mrt_render", "mrt_render_device", "mrt_scatter_strips",
     "mrt_intersect",
 ]
 
@@ -58,7 +58,7 @@ class Camera(C.Structure):
 
 
 class Partition(C.Structure):
-    _fields_ = [("rank", C.c_int32), ("num_ranks", C.c_int32), ("strip_rows", C.c_int32)]
+    _fields_ = [("rank", C.c_int32), ("num_ranks", C.c_int32), ("strip_rows", C.c_int32), ("frame_layout", C.c_int32)]
 
 
 class RenderParams(C.Structure):
@@ -107,8 +107,8 @@ def libmrt():
                                  C.c_void_p, C.POINTER(Stats)]
         L.mrt_render_device.argtypes = [C.c_void_p, C.POINTER(Camera), C.POINTER(RenderParams), C.c_void_p,
                                         C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
-        L.mrt_assemble_strips.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_int32, C.c_int32,
-                                          C.c_int32, C.c_int32, C.c_int32, C.c_void_p]
+        L.mrt_scatter_strips.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,
+                                         C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]
         L.mrt_intersect.argtypes = [C.c_void_p, C.c_int, _f, _f, C.c_float, C.c_float, C.c_int64, _u8, _f, _f, _f]
         _libmrt = L
     return _libmrt
@@ -128,6 +128,10 @@ def libhost():
         L.rth_flat_scene_destroy.argtypes = [C.c_void_p]
         L.rth_flat_scene_desc.argtypes = [C.c_void_p, C.POINTER(SceneDesc)]
         L.rth_msmesh_offsets.argtypes = [C.c_float, C.c_float, _f]
+        L.rth_sphere_can_hit.argtypes = [_f, C.c_float, _f, _f]
+        L.rth_triangle_can_hit.argtypes = [_f, _f, _f]
+        L.rth_default_scene_transformed_create.argtypes = [_f, _f]
+        L.rth_default_scene_transformed_create.restype = C.c_void_p
         _libhost = L
     return _libhost
 
@@ -211,6 +215,18 @@ class HostBuffer:
             pass
 
 
+def sphere_can_hit(center, radius, origin, direction):
+    """rt::Sphere::can_hit through rt::SceneObject (host C++)."""
+    a = [np.ascontiguousarray(v, dtype=np.float32) for v in (center, origin, direction)]
+    return bool(libhost().rth_sphere_can_hit(_fp(a[0]), float(radius), _fp(a[1]), _fp(a[2])))
+
+
+def triangle_can_hit(verts, origin, direction):
+    """rt::Triangle::can_hit through rt::SceneObject (host C++); verts [3, 3]."""
+    a = [np.ascontiguousarray(v, dtype=np.float32).reshape(-1) for v in (verts, origin, direction)]
+    return bool(libhost().rth_triangle_can_hit(_fp(a[0]), _fp(a[1]), _fp(a[2])))
+
+
 def directional_light_dir(d):
     a = np.asarray(d, dtype=np.float32)
     out = np.zeros(3, dtype=np.float32)
@@ -271,10 +287,16 @@ class FlatScene:
         return d
 
     @classmethod
-    def default(cls):
-        """The reference's hard-coded scene, built and flattened by the C++ host layer."""
+    def default(cls, rotation=None, translation=None):
+        """The reference's hard-coded scene, built and flattened by the C++ host layer; with a rotation (3x3) and a
+        translation, rt::Transform is applied to every object first (SceneObject::apply_transform)."""
         H = libhost()
-        h = C.c_void_p(H.rth_default_scene_create())
+        if rotation is None and translation is None:
+            h = C.c_void_p(H.rth_default_scene_create())
+        else:
+            r = np.ascontiguousarray(np.eye(3) if rotation is None else rotation, dtype=np.float32).reshape(9)
+            t = np.ascontiguousarray(np.zeros(3) if translation is None else translation, dtype=np.float32).reshape(3)
+            h = C.c_void_p(H.rth_default_scene_transformed_create(_fp(r), _fp(t)))
         try:
             d = SceneDesc()
             H.rth_flat_scene_desc(h, C.byref(d))
@@ -354,8 +376,8 @@ class Context:
                            f"{self._L.mrt_last_error(self._h).decode()}")
 
     def set_cull(self, mode):
-        """Render kernel: 0/False brute force, 1/True automatic (default), 2 one-level culling,
-        3 / 4 two-level culling with 4 / 8 waves, 5 the small-scene kernel.  Identical outputs."""
+        """Render kernel: 0/False brute force, 1/True automatic (default), 2 tile culling over the primitive
+        hierarchy, 5 the small-scene kernel.  Identical outputs."""
         mode = int(mode)
         self._check(self._L.mrt_ctx_set_option(self._h, 1, mode), "mrt_ctx_set_option")
         self.cull = mode
@@ -364,15 +386,19 @@ class Context:
         """Seed of the per-pixel random streams of diffuse bounces (default 1984, as the reference)."""
         self._check(self._L.mrt_ctx_set_option(self._h, 2, int(seed)), "mrt_ctx_set_option")
 
+    def fail_next_upload(self):
+        """Test hook (MRT_OPT_FAIL_NEXT_UPLOAD): the next upload fails at its device allocation."""
+        self._check(self._L.mrt_ctx_set_option(self._h, 3, 1), "mrt_ctx_set_option")
+
     def upload(self, flat):
         d = flat.desc()
         self._check(self._L.mrt_scene_upload(self._h, C.byref(d)), "mrt_scene_upload")
 
     @staticmethod
-    def _params(W, H, spp, max_depth, rank, num_ranks, strip_rows):
+    def _params(W, H, spp, max_depth, rank, num_ranks, strip_rows, frame_layout=0):
         p = RenderParams()
         p.width, p.height, p.spp, p.max_depth = W, H, spp, max_depth
-        p.part = Partition(rank, num_ranks, strip_rows)
+        p.part = Partition(rank, num_ranks, strip_rows, frame_layout)
         return p
 
     def render(self, cam12, W, H, spp=1, max_depth=0, rank=0, num_ranks=1, strip_rows=8, want_stats=True):
@@ -403,22 +429,24 @@ class Context:
         return st.as_dict()
 
     def render_device(self, cam12, W, H, rgb_ptr, id_ptr=None, t_ptr=None, stats_ptr=None, stream=None, spp=1,
-                      max_depth=0, rank=0, num_ranks=1, strip_rows=8):
-        """Asynchronous render into device buffers (raw pointers, e.g. torch tensor.data_ptr())."""
+                      max_depth=0, rank=0, num_ranks=1, strip_rows=8, frame_layout=0):
+        """Asynchronous render into device buffers (raw pointers, e.g. torch tensor.data_ptr()): the rank's rows
+        back to back, or (frame_layout=1) at their final places in whole-frame buffers."""
         cam = Camera.from12(cam12)
-        p = self._params(W, H, spp, max_depth, rank, num_ranks, strip_rows)
-        rc = self._L.mrt_render_device(self._h, C.byref(cam), C.byref(p), C.c_void_p(rgb_ptr),
-                                       C.c_void_p(id_ptr) if id_ptr else None, C.c_void_p(t_ptr) if t_ptr else None,
-                                       C.c_void_p(stats_ptr) if stats_ptr else None,
-                                       C.c_void_p(stream) if stream else None)
+        p = self._params(W, H, spp, max_depth, rank, num_ranks, strip_rows, frame_layout)
+        rc = self._L.mrt_render_device(self._h, C.byref(cam), C.byref(p), C.c_void_p(rgb_ptr), C.c_void_p(id_ptr) if id_ptr else None,
+                C.c_void_p(t_ptr) if t_ptr else None, C.c_void_p(stats_ptr) if stats_ptr else None,
+                C.c_void_p(stream) if stream else None)
         self._check(rc, "mrt_render_device")
 
-    def assemble_strips(self, gathered_ptr, rank_stride_elems, frame_ptr, W, H, elem_dwords, num_ranks, strip_rows=8,
-                        stream=None):
-        rc = self._L.mrt_assemble_strips(self._h, C.c_void_p(gathered_ptr), rank_stride_elems, C.c_void_p(frame_ptr),
-                                         W, H, elem_dwords, num_ranks, strip_rows,
-                                         C.c_void_p(stream) if stream else None)
-        self._check(rc, "mrt_assemble_strips")
+    def scatter_strips(self, staging_ptr, rgb_ptr, id_ptr, t_ptr, W, H, num_ranks, strip_rows=8, skip_rank=0,
+                       stream=None):
+        """Rank 0 after the gather: the packed buffers of the ranks other than skip_rank (in rank order at
+        staging_ptr) go to their strips' places in the three frame planes."""
+        rc = self._L.mrt_scatter_strips(self._h, C.c_void_p(staging_ptr), C.c_void_p(rgb_ptr),
+                                        C.c_void_p(id_ptr) if id_ptr else None, C.c_void_p(t_ptr) if t_ptr else None,
+                                        W, H, num_ranks, strip_rows, skip_rank, C.c_void_p(stream) if stream else None)
+        self._check(rc, "mrt_scatter_strips")
 
     def intersect(self, prim_kind, prim, rays, tmin, tmax):
         """Batched hit test of one primitive against rays [n,6] (origin, direction)."""

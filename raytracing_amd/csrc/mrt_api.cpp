@@ -38,9 +38,10 @@ struct mrt_ctx {
   unsigned long long *stats_dev = nullptr;
   int cull = 1; // MRT_OPT_CULL value
 
-  // u = col / W, v = row / H tables of the small-scene kernel, for the frame size of the last render
-  float *uv_mem = nullptr;
-  int uv_w = 0, uv_h = 0, uv_nu = 0;
+  // u = col / W, v = row / H tables of the small-scene kernel, one entry per frame size seen, kept until the
+  // context goes (a frame size costs (W + H) floats)
+  struct UvTables { int W, H, nu; float *mem; };
+  std::vector<UvTables> uv;
   // host copy of the triangles of a small scene (16 floats each, device order): the small-scene kernel's
   // launcher derives the camera-dependent culling functions from it for every render
   std::vector<float> small_tri16, small_sph;
@@ -56,6 +57,15 @@ struct mrt_ctx {
   uint32_t *bounce_scratch = nullptr;
   size_t bounce_scratch_words = 0;
 
+  // Renders of one context share stats_dev and the scratch above, so they are ordered on the GPU: a render on
+  // another stream than the last one waits for it (order_after_last).  Buffers a render in flight may still read
+  // are never freed under it: outgrown ones are parked here until the next point where the streams are drained.
+  hipStream_t last_stream = nullptr;
+  bool have_last = false;
+  hipEvent_t order_ev = nullptr;
+  std::vector<void *> retired;
+  size_t retired_bytes = 0;
+  bool fail_next_upload = false; // MRT_OPT_FAIL_NEXT_UPLOAD (test hook)
 };
 
 // the blocking entry point spreads its ray counters over this many copies (same-address atomics serialise: with
@@ -86,41 +96,86 @@ static int hip_fail(mrt_ctx *ctx, hipError_t e, const char *what)
   } while (0)
 
 // Kernel choice (MRT_OPT_CULL / environment MRT_CULL): 0 brute force (every ray x every primitive, like the
-// reference loops), 1 automatic (default), 2 one-level tile culling, 3 / 4 two-level culling with 4 / 8 waves,
-// 5 the small-scene kernel (at most 64 primitives; larger scenes fall back to 2).
-// All of them produce identical buffers (tests compare them).
+// reference loops), 1 automatic (default), 2 tile culling over the primitive hierarchy, 5 the small-scene kernel
+// (at most 64 primitives; larger scenes fall back to 2).  All of them produce identical buffers (tests compare them).
+static bool cull_mode_ok(int x) { return x == 0 || x == 1 || x == 2 || x == 5; }
+
 static int use_cull()
 {
   static const int v = [] {
     const char *e = getenv("MRT_CULL");
     const int x = e ? atoi(e) : 1;
-    return (x < 0 || x > 5) ? 1 : x;
+    return cull_mode_ok(x) ? x : 1;
   }();
   return v;
 }
 
-// The small-scene kernel reads u = col / W and v = row / H from tables; they are rebuilt (on the stream of the
-// render, followed by one synchronisation so that later renders on other streams may use them) only when the
-// frame size changes.
-static hipError_t ensure_uv_tables(mrt_ctx *ctx, int W, int H, hipStream_t st)
+// The next render goes to stream st: if the last one went to another stream, st waits for it (on the GPU).
+static hipError_t order_after_last(mrt_ctx *ctx, hipStream_t st)
 {
-  if (ctx->uv_mem && ctx->uv_w == W && ctx->uv_h == H) return hipSuccess;
-  hipError_t e;
-  if (ctx->uv_mem) {
-    if ((e = hipDeviceSynchronize()) != hipSuccess) return e; // a render in flight may still read the old tables
-    (void)hipFree(ctx->uv_mem);
-    ctx->uv_mem = nullptr;
+  if (ctx->have_last && ctx->last_stream != st) {
+    hipError_t e = hipEventRecord(ctx->order_ev, ctx->last_stream);
+    if (e == hipSuccess) e = hipStreamWaitEvent(st, ctx->order_ev, 0);
+    else { // the caller destroyed that stream (which waits for its work): nothing left to order against
+      (void)hipGetLastError();
+      e = hipSuccess;
+    }
+    if (e != hipSuccess) return e;
   }
-  const int nu = (W + 31) / 32 * 32; // whole tiles of up to 32 pixels
-  if ((e = hipMalloc((void **)&ctx->uv_mem, sizeof(float) * ((size_t)nu + H))) != hipSuccess) return e;
-  if ((e = mrt::launch_uv_table(ctx->uv_mem, nu, W, ctx->uv_mem + nu, H, H, st)) != hipSuccess) return e;
-  if ((e = hipStreamSynchronize(st)) != hipSuccess) return e;
-  ctx->uv_w = W; ctx->uv_h = H; ctx->uv_nu = nu;
+  ctx->last_stream = st;
+  ctx->have_last = true;
+  return hipSuccess;
+}
+
+// Waits (on the host) for everything this context has enqueued; then nothing reads the parked buffers any more.
+static hipError_t drain(mrt_ctx *ctx)
+{
+  hipError_t e = hipStreamSynchronize(ctx->stream);
+  if (e != hipSuccess) return e;
+  if (ctx->have_last && ctx->last_stream != ctx->stream) {
+    e = hipStreamSynchronize(ctx->last_stream);
+    if (e != hipSuccess) (void)hipGetLastError(); // stream destroyed by the caller: its work is done
+  }
+  for (void *p : ctx->retired) (void)hipFree(p);
+  ctx->retired.clear();
+  ctx->retired_bytes = 0;
+  return hipSuccess;
+}
+
+static hipError_t retire(mrt_ctx *ctx, void *p, size_t bytes)
+{
+  if (!p) return hipSuccess;
+  try { ctx->retired.push_back(p); } catch (...) { return hipErrorOutOfMemory; }
+  ctx->retired_bytes += bytes;
+  // a caller that keeps growing its frames: give the memory back once it adds up
+  return ctx->retired_bytes > ((size_t)1 << 30) ? drain(ctx) : hipSuccess;
+}
+
+// The small-scene kernel reads u = col / W and v = row / H from tables.  A new frame size gets its own pair, built
+// on the stream of the render ahead of it; renders of one context are ordered (order_after_last), so every later
+// render, on whatever stream, runs after the build.  Nothing is freed or synchronised here.
+static hipError_t ensure_uv_tables(mrt_ctx *ctx, int W, int H, hipStream_t st, const float **utab, const float **vtab)
+{
+  for (const auto &u : ctx->uv)
+    if (u.W == W && u.H == H) { *utab = u.mem; *vtab = u.mem + u.nu; return hipSuccess; }
+  hipError_t e;
+  if (ctx->uv.size() >= 256) { // a caller cycling through frame sizes: start over
+    if ((e = drain(ctx)) != hipSuccess) return e;
+    for (auto &u : ctx->uv) (void)hipFree(u.mem);
+    ctx->uv.clear();
+  }
+  mrt_ctx::UvTables u{W, H, (W + 31) / 32 * 32, nullptr}; // whole tiles of up to 32 pixels
+  try { ctx->uv.reserve(ctx->uv.size() + 1); } catch (...) { return hipErrorOutOfMemory; }
+  if ((e = hipMalloc((void **)&u.mem, sizeof(float) * ((size_t)u.nu + H))) != hipSuccess) return e;
+  if ((e = mrt::launch_uv_table(u.mem, u.nu, W, u.mem + u.nu, H, H, st)) != hipSuccess) { (void)hipFree(u.mem); return e; }
+  ctx->uv.push_back(u);
+  *utab = u.mem; *vtab = u.mem + u.nu;
   return hipSuccess;
 }
 
 // Streams 0..npix-1 (the stream of a pixel is its index in the FULL frame, src/main.cu:133, whatever strip
-// partition renders it).  Built on the context's stream and synchronised once, like the u/v tables.
+// partition renders it).  Built on the context's stream after the last render (which may still read the old
+// states) and waited for on the host: first need, a larger frame or a new seed only.
 static hipError_t ensure_rng_states(mrt_ctx *ctx, size_t npix)
 {
   if (ctx->rng_mem && ctx->rng_n >= npix && ctx->rng_built_seed == ctx->rng_seed) return hipSuccess;
@@ -131,49 +186,48 @@ static hipError_t ensure_rng_states(mrt_ctx *ctx, size_t npix)
     if ((e = hipMemcpy(ctx->rng_jump, mrt::rng_jump_tables(), bytes, hipMemcpyHostToDevice)) != hipSuccess) return e;
   }
   if (ctx->rng_n < npix) {
-    if (ctx->rng_mem) {
-      if ((e = hipDeviceSynchronize()) != hipSuccess) return e; // a render in flight may still read the old buffer
-      (void)hipFree(ctx->rng_mem);
-      ctx->rng_mem = nullptr; ctx->rng_n = 0;
-    }
+    if ((e = retire(ctx, ctx->rng_mem, 5 * (size_t)ctx->rng_n * sizeof(uint32_t))) != hipSuccess) return e;
+    ctx->rng_mem = nullptr; ctx->rng_n = 0;
     const size_t n = (npix + 1023) / 1024 * 1024;
     if ((e = hipMalloc((void **)&ctx->rng_mem, 5 * n * sizeof(uint32_t))) != hipSuccess) return e;
     ctx->rng_n = (uint32_t)n;
-  } else if ((e = hipDeviceSynchronize()) != hipSuccess) return e; // new seed: same buffer, rebuilt
+  }
+  if ((e = order_after_last(ctx, ctx->stream)) != hipSuccess) return e;
   if ((e = mrt::launch_rng_init(ctx->rng_jump, ctx->rng_mem, ctx->rng_n, ctx->rng_n, ctx->rng_seed, ctx->stream)) != hipSuccess) return e;
   if ((e = hipStreamSynchronize(ctx->stream)) != hipSuccess) return e;
   ctx->rng_built_seed = ctx->rng_seed;
   return hipSuccess;
 }
 
+static mrt::SmallHost small_host(const mrt_ctx *ctx)
+{
+  mrt::SmallHost hs;
+  hs.ns = (int)ctx->small_sph_obj.size(); hs.nt = (int)ctx->small_tri_obj.size();
+  hs.sph = ctx->small_sph.data(); hs.sph_obj = ctx->small_sph_obj.data();
+  hs.tri16 = ctx->small_tri16.data(); hs.tri_obj = ctx->small_tri_obj.data();
+  return hs;
+}
+
 static hipError_t launch_by_mode(mrt_ctx *ctx, mrt::RenderArgs &A, hipStream_t st)
 {
-  if (A.max_depth > 0) { // bounce chains: one kernel, every ray x every primitive
+  hipError_t e;
+  if (A.max_depth > 0) { // bounce chains: one kernel
     if (ctx->any_diffuse) {
-      hipError_t e = ensure_rng_states(ctx, (size_t)A.W * A.H);
-      if (e != hipSuccess) return e;
+      if ((e = ensure_rng_states(ctx, (size_t)A.W * A.H)) != hipSuccess) return e;
       uint32_t v[5];
       mrt::rng_seed_state(ctx->rng_seed, v, &A.rng_d);
       A.rng = ctx->rng_mem; A.rng_stride = ctx->rng_n;
     }
+    if ((e = order_after_last(ctx, st)) != hipSuccess) return e;
     // MRT_OPT_CULL = 0 keeps the small-scene culling data out of it (every ray walks the hierarchy: cross-check)
     const bool small = (long)A.sc.ns + A.sc.nt <= 64 && ctx->cull != 0;
-    mrt::SmallHost hs;
-    if (small) {
-      hs.ns = (int)ctx->small_sph_obj.size(); hs.nt = (int)ctx->small_tri_obj.size();
-      hs.sph = ctx->small_sph.data(); hs.sph_obj = ctx->small_sph_obj.data();
-      hs.tri16 = ctx->small_tri16.data(); hs.tri_obj = ctx->small_tri_obj.data();
-    }
+    const mrt::SmallHost hs = small_host(ctx);
     uint32_t *scratch = nullptr;
     if (small && A.spp > 1) {
       const size_t need = mrt::bounce_scratch_words(A.W, A.local_rows);
       if (ctx->bounce_scratch_words < need) {
-        hipError_t e;
-        if (ctx->bounce_scratch) {
-          if ((e = hipDeviceSynchronize()) != hipSuccess) return e; // a render in flight may still read the old one
-          (void)hipFree(ctx->bounce_scratch);
-          ctx->bounce_scratch = nullptr; ctx->bounce_scratch_words = 0;
-        }
+        if ((e = retire(ctx, ctx->bounce_scratch, ctx->bounce_scratch_words * sizeof(uint32_t))) != hipSuccess) return e;
+        ctx->bounce_scratch = nullptr; ctx->bounce_scratch_words = 0;
         if ((e = hipMalloc((void **)&ctx->bounce_scratch, need * sizeof(uint32_t))) != hipSuccess) return e;
         ctx->bounce_scratch_words = need;
       }
@@ -181,27 +235,19 @@ static hipError_t launch_by_mode(mrt_ctx *ctx, mrt::RenderArgs &A, hipStream_t s
     }
     return mrt::launch_render_bounce(A, small ? &hs : nullptr, scratch, st);
   }
+  if ((e = order_after_last(ctx, st)) != hipSuccess) return e;
   int mode = ctx->cull;
   const bool small = (long)A.sc.ns + A.sc.nt <= 64;
   // measured: the small-scene kernel wins where it applies; with the primitive-side hierarchy the
-  // one-level tile kernel wins everywhere else
+  // tile-culling kernel wins everywhere else
   if (mode == 1) mode = small ? 5 : 2;
   if (mode == 5 && !small) mode = 2;
   switch (mode) {
   case 0: return mrt::launch_render(A, st);
   case 2: return mrt::launch_render_cull(A, st);
-  case 3: return mrt::launch_render_cull2(A, 4, st);
-  case 4: return mrt::launch_render_cull2(A, 8, st);
-  default: {
-    hipError_t e = ensure_uv_tables(ctx, A.W, A.H, st);
-    if (e != hipSuccess) return e;
-    A.utab = ctx->uv_mem; A.vtab = ctx->uv_mem + ctx->uv_nu;
-    mrt::SmallHost hs;
-    hs.ns = (int)ctx->small_sph_obj.size(); hs.nt = (int)ctx->small_tri_obj.size();
-    hs.sph = ctx->small_sph.data(); hs.sph_obj = ctx->small_sph_obj.data();
-    hs.tri16 = ctx->small_tri16.data(); hs.tri_obj = ctx->small_tri_obj.data();
-    return mrt::launch_render_small(A, hs, st);
-  }
+  default:
+    if (!A.utab && (e = ensure_uv_tables(ctx, A.W, A.H, st, &A.utab, &A.vtab)) != hipSuccess) return e;
+    return mrt::launch_render_small(A, small_host(ctx), st);
   }
 }
 
@@ -211,8 +257,12 @@ int mrt_ctx_set_option(mrt_ctx *ctx, int option, int value)
 {
   if (!ctx) return MRT_ERR_INVALID;
   if (option == MRT_OPT_CULL) {
-    if (value < 0 || value > 5) return fail(ctx, MRT_ERR_INVALID, "MRT_OPT_CULL takes 0..5");
+    if (!cull_mode_ok(value)) return fail(ctx, MRT_ERR_INVALID, "MRT_OPT_CULL takes 0, 1, 2 or 5");
     ctx->cull = value;
+    return MRT_OK;
+  }
+  if (option == MRT_OPT_FAIL_NEXT_UPLOAD) {
+    ctx->fail_next_upload = value != 0;
     return MRT_OK;
   }
   if (option == MRT_OPT_RNG_SEED) {
@@ -269,6 +319,7 @@ int mrt_ctx_create(int device, mrt_ctx **out)
   if ((e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)) != hipSuccess) return bail(e, "hipStreamCreate");
   if ((e = hipEventCreate(&ctx->ev0)) != hipSuccess) return bail(e, "hipEventCreate");
   if ((e = hipEventCreate(&ctx->ev1)) != hipSuccess) return bail(e, "hipEventCreate");
+  if ((e = hipEventCreateWithFlags(&ctx->order_ev, hipEventDisableTiming)) != hipSuccess) return bail(e, "hipEventCreate");
   if ((e = hipMalloc((void **)&ctx->stats_dev, STATS_SLOTS * 8 * sizeof(unsigned long long))) != hipSuccess) return bail(e, "hipMalloc");
   *out = ctx;
   return MRT_OK;
@@ -278,9 +329,9 @@ int mrt_ctx_destroy(mrt_ctx *ctx)
 {
   if (!ctx) return MRT_OK;
   (void)hipSetDevice(ctx->device);
-  if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+  if (ctx->stream) (void)drain(ctx);
   if (ctx->scene_mem) (void)hipFree(ctx->scene_mem);
-  if (ctx->uv_mem) (void)hipFree(ctx->uv_mem);
+  for (auto &u : ctx->uv) (void)hipFree(u.mem);
   if (ctx->rng_mem) (void)hipFree(ctx->rng_mem);
   if (ctx->rng_jump) (void)hipFree(ctx->rng_jump);
   if (ctx->bounce_scratch) (void)hipFree(ctx->bounce_scratch);
@@ -288,6 +339,7 @@ int mrt_ctx_destroy(mrt_ctx *ctx)
   if (ctx->stats_dev) (void)hipFree(ctx->stats_dev);
   if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
   if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+  if (ctx->order_ev) (void)hipEventDestroy(ctx->order_ev);
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
   return MRT_OK;
@@ -372,6 +424,9 @@ int mrt_scene_upload(mrt_ctx *ctx, const mrt_scene_desc *s)
 
   std::vector<unsigned char> img;
   try { img.assign(total, 0); } catch (...) { return fail(ctx, MRT_ERR_INVALID, "out of host memory"); }
+  // host copy of a small scene (device order), committed to the context together with the device scene
+  std::vector<float> new_tri16, new_sph;
+  std::vector<int32_t> new_tri_obj, new_sph_obj;
   auto put = [&](size_t o, const void *src, size_t bytes) { if (bytes) std::memcpy(img.data() + o, src, bytes); };
   {
     // spheres, in kd order
@@ -387,11 +442,10 @@ int mrt_scene_upload(mrt_ctx *ctx, const mrt_scene_desc *s)
       so[i] = s->sphere_obj[g];
     }
     try {
-      ctx->small_sph.clear(); ctx->small_sph_obj.clear();
-      if (ns + nt <= 64)
+      if (small)
         for (size_t i = 0; i < ns; ++i) {
-          ctx->small_sph.insert(ctx->small_sph.end(), {cx[i], cy[i], cz[i], r[i]});
-          ctx->small_sph_obj.push_back(so[i]);
+          new_sph.insert(new_sph.end(), {cx[i], cy[i], cz[i], r[i]});
+          new_sph_obj.push_back(so[i]);
         }
     } catch (...) { return fail(ctx, MRT_ERR_INVALID, "out of host memory"); }
     // a sphere's own ball must contain it even for a negative radius: the hit test only sees r*r
@@ -428,10 +482,8 @@ int mrt_scene_upload(mrt_ctx *ctx, const mrt_scene_desc *s)
         for (int k = 0; k < SH_STRIDE; ++k) shfn[(l * SH_STRIDE + k) * nt + i] = f[k];
       }
     try {
-      if (small) { ctx->small_tri16.assign(rec, rec + 16 * nt); ctx->small_tri_obj.assign(to, to + nt); }
-      else { ctx->small_tri16.clear(); ctx->small_tri_obj.clear(); }
-    }
-    catch (...) { return fail(ctx, MRT_ERR_INVALID, "out of host memory"); }
+      if (small) { new_tri16.assign(rec, rec + 16 * nt); new_tri_obj.assign(to, to + nt); }
+    } catch (...) { return fail(ctx, MRT_ERR_INVALID, "out of host memory"); }
     float *ct = (float *)(img.data() + o_ct);
     cluster_bounds(bnd, bnd + nt, bnd + 2 * nt, bnd + 3 * nt, nt, ct);
     cluster_bounds(ct, ct + nct, ct + 2 * nct, ct + 3 * nct, nct, (float *)(img.data() + o_sct));
@@ -440,13 +492,21 @@ int mrt_scene_upload(mrt_ctx *ctx, const mrt_scene_desc *s)
   put(o_lk, s->light_kind, nl);    put(o_lv, s->light_vec, nl * 12); put(o_lc, s->light_rgb, nl * 12);
 
   HIP_TRY(ctx, hipSetDevice(ctx->device));
-  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  HIP_TRY(ctx, drain(ctx)); // renders in flight still read the old scene
+  // from here on the old scene is given up: whatever fails below leaves the context without one
+  ctx->have_scene = false;
+  ctx->any_diffuse = false;
+  ctx->small_sph.clear(); ctx->small_sph_obj.clear(); ctx->small_tri16.clear(); ctx->small_tri_obj.clear();
+  if (ctx->fail_next_upload) {
+    ctx->fail_next_upload = false;
+    if (ctx->scene_mem) { (void)hipFree(ctx->scene_mem); ctx->scene_mem = nullptr; ctx->scene_bytes = 0; }
+    return fail(ctx, MRT_ERR_HIP, "HIP error: injected allocation failure (MRT_OPT_FAIL_NEXT_UPLOAD) in mrt_scene_upload");
+  }
   if (ctx->scene_bytes < total) {
-    if (ctx->scene_mem) { HIP_TRY(ctx, hipFree(ctx->scene_mem)); ctx->scene_mem = nullptr; ctx->scene_bytes = 0; }
+    if (ctx->scene_mem) { void *old = ctx->scene_mem; ctx->scene_mem = nullptr; ctx->scene_bytes = 0; HIP_TRY(ctx, hipFree(old)); }
     HIP_TRY(ctx, hipMalloc(&ctx->scene_mem, total));
     ctx->scene_bytes = total;
   }
-  ctx->have_scene = false;
   HIP_TRY(ctx, hipMemcpy(ctx->scene_mem, img.data(), total, hipMemcpyHostToDevice));
 
   unsigned char *b = (unsigned char *)ctx->scene_mem;
@@ -464,15 +524,17 @@ int mrt_scene_upload(mrt_ctx *ctx, const mrt_scene_desc *s)
   d.mat_kind = b + o_mk; d.mat_rgb = (const float *)(b + o_mrgb); d.nobj = (int32_t)no;
   d.light_kind = b + o_lk; d.light_vec = (const float *)(b + o_lv); d.light_rgb = (const float *)(b + o_lc);
   d.nl = (int32_t)nl;
-  ctx->any_diffuse = false;
   for (size_t i = 0; i < no; ++i) ctx->any_diffuse |= (s->mat_kind[i] == MRT_MAT_DIFFUSE);
+  ctx->small_sph.swap(new_sph); ctx->small_sph_obj.swap(new_sph_obj);
+  ctx->small_tri16.swap(new_tri16); ctx->small_tri_obj.swap(new_tri_obj);
   ctx->have_scene = true;
   return MRT_OK;
 }
 
 static bool partition_ok(const mrt_partition &p)
 {
-  return p.num_ranks >= 1 && p.rank >= 0 && p.rank < p.num_ranks && p.strip_rows >= 8 && (p.strip_rows % 8) == 0;
+  return p.num_ranks >= 1 && p.rank >= 0 && p.rank < p.num_ranks && p.strip_rows >= 8 && (p.strip_rows % 8) == 0 &&
+         (p.frame_layout == 0 || p.frame_layout == 1);
 }
 
 static int local_rows_of(int H, const mrt_partition &p)
@@ -513,6 +575,7 @@ static int fill_args(mrt_ctx *ctx, const mrt_camera *cam, const mrt_render_param
   A.W = p->width; A.H = p->height;
   A.rank = p->part.rank; A.nranks = p->part.num_ranks; A.strip_rows = p->part.strip_rows;
   A.local_rows = local_rows_of(p->height, p->part);
+  A.frame_layout = p->part.frame_layout;
   A.spp = p->spp;
   A.max_depth = p->max_depth;
   A.stats_slots = 1;
@@ -546,6 +609,7 @@ int mrt_render(mrt_ctx *ctx, const mrt_camera *cam, const mrt_render_params *par
   int rc = fill_args(ctx, cam, params, A);
   if (rc != MRT_OK) return rc;
   if (!rgb) return fail(ctx, MRT_ERR_INVALID, "rgb buffer is required");
+  if (A.frame_layout != 0) return fail(ctx, MRT_ERR_INVALID, "mrt_render takes frame_layout 0 (a rank's rows back to back)");
   const size_t npix = (size_t)A.local_rows * A.W;
   const size_t need = npix * 20 + 256;
   HIP_TRY(ctx, hipSetDevice(ctx->device));
@@ -589,21 +653,30 @@ int mrt_render(mrt_ctx *ctx, const mrt_camera *cam, const mrt_render_params *par
   return MRT_OK;
 }
 
-int mrt_assemble_strips(mrt_ctx *ctx, const void *gathered_dev, size_t rank_stride_elems, void *frame_dev, int32_t width,
-                        int32_t height, int32_t elem_dwords, int32_t num_ranks, int32_t strip_rows, void *stream)
+int mrt_scatter_strips(mrt_ctx *ctx, const void *staging_dev, void *frame_rgb_dev, void *frame_id_dev, void *frame_t_dev,
+                       int32_t width, int32_t height, int32_t num_ranks, int32_t strip_rows, int32_t skip_rank, void *stream)
 {
-  if (!ctx || !gathered_dev || !frame_dev) return MRT_ERR_INVALID;
-  if (width <= 0 || height <= 0 || elem_dwords <= 0 || num_ranks <= 0 || strip_rows <= 0)
-    return fail(ctx, MRT_ERR_INVALID, "bad assemble shape");
-  mrt_partition p0{0, num_ranks, strip_rows};
-  if (!partition_ok(p0)) return fail(ctx, MRT_ERR_INVALID, "bad strip partition");
-  // rank 0 holds the most rows; every rank's slab must fit in the stride
-  if ((size_t)local_rows_of(height, p0) * width * elem_dwords > rank_stride_elems)
-    return fail(ctx, MRT_ERR_INVALID, "rank stride smaller than a rank's strip buffer");
+  if (!ctx) return MRT_ERR_INVALID;
+  if (!staging_dev || !frame_rgb_dev) return fail(ctx, MRT_ERR_INVALID, "staging and rgb frame buffers are required");
+  if (width <= 0 || height <= 0) return fail(ctx, MRT_ERR_INVALID, "non-positive frame size");
+  if (num_ranks > mrt::MAX_RANKS) return fail(ctx, MRT_ERR_TOO_LARGE, "more than 64 ranks");
+  if (skip_rank < -1 || skip_rank >= num_ranks) return fail(ctx, MRT_ERR_INVALID, "skip_rank out of range");
+  mrt_partition p{0, num_ranks, strip_rows, 0};
+  if (!partition_ok(p)) return fail(ctx, MRT_ERR_INVALID, "bad strip partition");
+  mrt::ScatterArgs S;
+  std::memset(&S, 0, sizeof S);
+  S.staging = (const uint32_t *)staging_dev;
+  S.rgb = (uint32_t *)frame_rgb_dev; S.id = (uint32_t *)frame_id_dev; S.t = (uint32_t *)frame_t_dev;
+  S.W = width; S.H = height; S.nranks = num_ranks; S.strip_rows = strip_rows; S.skip_rank = skip_rank;
+  uint64_t off = 0;
+  for (int r = 0; r < num_ranks; ++r) {
+    p.rank = r;
+    S.rank_rows[r] = local_rows_of(height, p);
+    S.rank_off[r] = off;
+    if (r != skip_rank) off += (uint64_t)S.rank_rows[r] * (uint64_t)width * 5;
+  }
   HIP_TRY(ctx, hipSetDevice(ctx->device));
-  hipStream_t st = (hipStream_t)stream;
-  HIP_TRY(ctx, mrt::launch_assemble((const uint32_t *)gathered_dev, rank_stride_elems, (uint32_t *)frame_dev, width,
-                                    height, elem_dwords, num_ranks, strip_rows, st));
+  HIP_TRY(ctx, mrt::launch_scatter(S, (hipStream_t)stream));
   return MRT_OK;
 }
 
