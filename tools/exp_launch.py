@@ -7,7 +7,7 @@ from raytracing_amd import capi, scenes, multigpu
 flat, cam = scenes.default_scene()
 W, H = 1920, 1080
 cam12 = capi.viewport(cam["look_from"], cam["look_at"], cam["up"], cam["vfov"], W / H)
-fr = multigpu.FrameRenderer(flat, cam12, W, H, with_ids=True)
+fr = multigpu.FrameRenderer(flat, cam12, W, H)
 for _ in range(50):
     fr.render_local()
 torch.cuda.synchronize()

@@ -15,7 +15,7 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
                 "C4m": lambda: scenes.triangle_terrain(300, 150)}[cfg]()
         W, H = (3840, 2160) if cfg in ("C3", "C4", "C4m") else (1920, 1080)
         flat = spec.flatten(); cam12 = spec.cam12(W / H)
-    fr = multigpu.FrameRenderer(flat, cam12, W, H, with_ids=True)
+    fr = multigpu.FrameRenderer(flat, cam12, W, H)
     n = 200 if cfg == "C2" else 5
     for _ in range(max(2, n // 10)): fr.render_local()
     torch.cuda.synchronize(); t0 = time.perf_counter()
