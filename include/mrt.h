@@ -198,6 +198,19 @@ int mrt_render_device(mrt_ctx *ctx, const mrt_camera *cam, const mrt_render_para
                       void *id_dev, void *t_dev, void *stats_dev, void *stream);
 
 /*
+ * mrt_render_device for callers that cannot allocate (no counterpart in the reference: it is for code under HIP
+ * graph capture, tight serving loops and harnesses that forbid hipMalloc).  Same arguments, same buffers, same
+ * results; it calls no hipMalloc / hipFree / allocating routine, ever.  What mrt_render_device keeps in allocated
+ * buffers -- the spread ray counters and the small-scene kernel's u / v tables -- lives in one static device array
+ * of 144 KB that every GPU the library runs on holds until the process ends.
+ * Limits: max_depth 0 only (MRT_ERR_INVALID otherwise; spp 1 or 121), frames of at most 16384 pixels a side
+ * (MRT_ERR_TOO_LARGE beyond).  Every call on a GPU -- from any context -- uses that GPU's one array: calls of
+ * different contexts that overlap on one GPU race (calls of ONE context are ordered as for mrt_render_device).
+ */
+int mrt_render_device_static(mrt_ctx *ctx, const mrt_camera *cam, const mrt_render_params *params, void *rgb_dev,
+                             void *id_dev, void *t_dev, void *stats_dev, void *stream);
+
+/*
  * Rank 0 of a multi-GPU frame, after the gather (no reference counterpart: SURVEY 8(e)).  Rank 0 has rendered
  * its own strips in place (frame_layout 1); every other rank r sent ONE packed buffer holding its local rows
  * back to back as three planes, rgb [rows_r*W*3] | id [rows_r*W] | t [rows_r*W] (4-byte elements, rows_r =

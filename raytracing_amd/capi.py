@@ -19,7 +19,7 @@ LIGHT_DIRECTIONAL, LIGHT_POINT = 0, 1
 # every symbol include/mrt.h declares (tests check the library exports all of them)
 MRT_SYMBOLS = [
     "mrt_device_count", "mrt_ctx_create", "mrt_ctx_destroy", "mrt_ctx_set_option", "mrt_last_error", "mrt_status_string",
-    "mrt_triangle_bound", "mrt_rng_state", "mrt_host_alloc", "mrt_host_free", "mrt_scene_upload", "mrt_local_rows", "mrt_render", "mrt_render_device", "mrt_scatter_strips",
+    "mrt_triangle_bound", "mrt_rng_state", "mrt_host_alloc", "mrt_host_free", "mrt_scene_upload", "mrt_local_rows", "mrt_render", "mrt_render_device", "mrt_render_device_static", "mrt_scatter_strips",
     "mrt_intersect",
 ]
 
@@ -107,6 +107,7 @@ def libmrt():
                                  C.c_void_p, C.POINTER(Stats)]
         L.mrt_render_device.argtypes = [C.c_void_p, C.POINTER(Camera), C.POINTER(RenderParams), C.c_void_p,
                                         C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.mrt_render_device_static.argtypes = L.mrt_render_device.argtypes
         L.mrt_scatter_strips.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,
                                          C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]
         L.mrt_intersect.argtypes = [C.c_void_p, C.c_int, _f, _f, C.c_float, C.c_float, C.c_int64, _u8, _f, _f, _f]
@@ -429,15 +430,17 @@ class Context:
         return st.as_dict()
 
     def render_device(self, cam12, W, H, rgb_ptr, id_ptr=None, t_ptr=None, stats_ptr=None, stream=None, spp=1,
-                      max_depth=0, rank=0, num_ranks=1, strip_rows=8, frame_layout=0):
+                      max_depth=0, rank=0, num_ranks=1, strip_rows=8, frame_layout=0, static=False):
         """Asynchronous render into device buffers (raw pointers, e.g. torch tensor.data_ptr()): the rank's rows
-        back to back, or (frame_layout=1) at their final places in whole-frame buffers."""
+        back to back, or (frame_layout=1) at their final places in whole-frame buffers.  static=True goes through
+        mrt_render_device_static, the entry point that allocates nothing."""
         cam = Camera.from12(cam12)
         p = self._params(W, H, spp, max_depth, rank, num_ranks, strip_rows, frame_layout)
-        rc = self._L.mrt_render_device(self._h, C.byref(cam), C.byref(p), C.c_void_p(rgb_ptr), C.c_void_p(id_ptr) if id_ptr else None,
+        fn = self._L.mrt_render_device_static if static else self._L.mrt_render_device
+        rc = fn(self._h, C.byref(cam), C.byref(p), C.c_void_p(rgb_ptr), C.c_void_p(id_ptr) if id_ptr else None,
                 C.c_void_p(t_ptr) if t_ptr else None, C.c_void_p(stats_ptr) if stats_ptr else None,
                 C.c_void_p(stream) if stream else None)
-        self._check(rc, "mrt_render_device")
+        self._check(rc, "mrt_render_device_static" if static else "mrt_render_device")
 
     def scatter_strips(self, staging_ptr, rgb_ptr, id_ptr, t_ptr, W, H, num_ranks, strip_rows=8, skip_rank=0,
                        stream=None):

@@ -66,6 +66,7 @@ struct mrt_ctx {
   std::vector<void *> retired;
   size_t retired_bytes = 0;
   bool fail_next_upload = false; // MRT_OPT_FAIL_NEXT_UPLOAD (test hook)
+  void *static_scratch = nullptr; // this GPU's copy of the allocation-free entry point's array (or null: see create)
 };
 
 // the blocking entry point spreads its ray counters over this many copies (same-address atomics serialise: with
@@ -73,6 +74,37 @@ struct mrt_ctx {
 enum { STATS_SLOTS = 256 };
 
 using namespace mrt::build;
+
+// ---- the allocation-free entry point's memory (mrt_render_device_static, include/mrt.h) ----
+// One file-scope device array per GPU the library runs on, held until the process ends: the render kernels' ray
+// counters (STATS_SLOTS copies of 8) and the small-scene kernel's u = col / W, v = row / H tables for frames of up
+// to STATIC_MAX_DIM pixels a side.  In host code `scratch` is only a stand-in for the symbol: the address on a
+// GPU comes from hipGetSymbolAddress with that GPU current (static_scratch_of, called by mrt_ctx_create), and
+// only that pointer is handed to kernels and memsets.
+enum { STATIC_MAX_DIM = 16384, STATIC_MAX_DEVICES = 64 };
+enum : size_t {
+  STATIC_STATS_BYTES = (size_t)STATS_SLOTS * 8 * sizeof(unsigned long long),
+  STATIC_UTAB_FLOATS = STATIC_MAX_DIM + 32, // whole tiles of up to 32 pixels
+  STATIC_SCRATCH_BYTES = STATIC_STATS_BYTES + (STATIC_UTAB_FLOATS + STATIC_MAX_DIM) * sizeof(float)
+};
+static __device__ __align__(256) unsigned char scratch[STATIC_SCRATCH_BYTES];
+static void *g_static_scratch[STATIC_MAX_DEVICES]; // per device: each GPU holds its own copy at its own address
+
+// the array's address on `device`, which must be the current device; resolved once per device
+static hipError_t static_scratch_of(int device, void **out)
+{
+  *out = nullptr;
+  if (device < 0 || device >= STATIC_MAX_DEVICES) return hipErrorInvalidDevice;
+  if (!g_static_scratch[device]) {
+    void *p = nullptr;
+    hipError_t e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
+    if (e != hipSuccess) return e;
+    if (!p) return hipErrorInvalidSymbol;
+    g_static_scratch[device] = p;
+  }
+  *out = g_static_scratch[device];
+  return hipSuccess;
+}
 
 static thread_local std::string g_create_err;
 
@@ -321,6 +353,8 @@ int mrt_ctx_create(int device, mrt_ctx **out)
   if ((e = hipEventCreate(&ctx->ev1)) != hipSuccess) return bail(e, "hipEventCreate");
   if ((e = hipEventCreateWithFlags(&ctx->order_ev, hipEventDisableTiming)) != hipSuccess) return bail(e, "hipEventCreate");
   if ((e = hipMalloc((void **)&ctx->stats_dev, STATS_SLOTS * 8 * sizeof(unsigned long long))) != hipSuccess) return bail(e, "hipMalloc");
+  // the allocation-free entry point's array on this GPU; a failure here only disables that entry point
+  if (static_scratch_of(device, &ctx->static_scratch) != hipSuccess) { (void)hipGetLastError(); ctx->static_scratch = nullptr; }
   *out = ctx;
   return MRT_OK;
 }
@@ -592,6 +626,7 @@ int mrt_render_device(mrt_ctx *ctx, const mrt_camera *cam, const mrt_render_para
   A.rgb = (float *)rgb_dev; A.id = (int32_t *)id_dev; A.t = (float *)t_dev;
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   hipStream_t st = (hipStream_t)stream; // NULL = HIP's default stream, as everywhere in HIP
+  HIP_TRY(ctx, order_after_last(ctx, st)); // before anything touches the shared counters
   if (stats_dev) { // counted in the context's spread copies, then added up into the caller's eight words
     A.stats = ctx->stats_dev;
     A.stats_slots = STATS_SLOTS;
@@ -599,6 +634,42 @@ int mrt_render_device(mrt_ctx *ctx, const mrt_camera *cam, const mrt_render_para
   }
   HIP_TRY(ctx, launch_by_mode(ctx, A, st));
   if (stats_dev) HIP_TRY(ctx, mrt::launch_stats_reduce(ctx->stats_dev, STATS_SLOTS, (unsigned long long *)stats_dev, st));
+  return MRT_OK;
+}
+
+int mrt_render_device_static(mrt_ctx *ctx, const mrt_camera *cam, const mrt_render_params *params, void *rgb_dev,
+                             void *id_dev, void *t_dev, void *stats_dev, void *stream)
+{
+  mrt::RenderArgs A;
+  int rc = fill_args(ctx, cam, params, A);
+  if (rc != MRT_OK) return rc;
+  if (!rgb_dev) return fail(ctx, MRT_ERR_INVALID, "rgb buffer is required");
+  if (A.max_depth != 0)
+    return fail(ctx, MRT_ERR_INVALID, "mrt_render_device_static renders max_depth 0 only (bounce chains need buffers sized by the frame)");
+  if (A.W > STATIC_MAX_DIM || A.H > STATIC_MAX_DIM)
+    return fail(ctx, MRT_ERR_TOO_LARGE, "mrt_render_device_static: frame larger than 16384 pixels in a dimension");
+  if (!ctx->static_scratch) return fail(ctx, MRT_ERR_HIP, "mrt_render_device_static: the static device array could not be resolved on this GPU");
+  A.rgb = (float *)rgb_dev; A.id = (int32_t *)id_dev; A.t = (float *)t_dev;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  hipStream_t st = (hipStream_t)stream;
+  unsigned char *sp = (unsigned char *)ctx->static_scratch;
+  unsigned long long *slots = (unsigned long long *)sp;
+  float *utab = (float *)(sp + STATIC_STATS_BYTES), *vtab = utab + STATIC_UTAB_FLOATS;
+  HIP_TRY(ctx, order_after_last(ctx, st));
+  if (stats_dev) { // the array keeps the last call's counts: clear them
+    A.stats = slots;
+    A.stats_slots = STATS_SLOTS;
+    HIP_TRY(ctx, hipMemsetAsync(slots, 0, STATIC_STATS_BYTES, st));
+  }
+  if ((long)A.sc.ns + A.sc.nt <= 64 && (ctx->cull == 1 || ctx->cull == 5)) {
+    // the small-scene kernel's tables: rebuilt on every call, on the caller's stream (the array is shared by every
+    // context on this GPU, so nothing is known about what the last call left in it)
+    const int nu = (A.W + 31) / 32 * 32;
+    HIP_TRY(ctx, mrt::launch_uv_table(utab, nu, A.W, vtab, A.H, A.H, st));
+    A.utab = utab; A.vtab = vtab;
+  }
+  HIP_TRY(ctx, launch_by_mode(ctx, A, st));
+  if (stats_dev) HIP_TRY(ctx, mrt::launch_stats_reduce(slots, STATS_SLOTS, (unsigned long long *)stats_dev, st));
   return MRT_OK;
 }
 
@@ -624,6 +695,7 @@ int mrt_render(mrt_ctx *ctx, const mrt_camera *cam, const mrt_render_params *par
   A.t = (float *)((char *)ctx->out_mem + npix * 16);
   A.stats = stats ? ctx->stats_dev : nullptr;
   A.stats_slots = STATS_SLOTS;
+  HIP_TRY(ctx, order_after_last(ctx, ctx->stream));
   if (A.stats) HIP_TRY(ctx, hipMemsetAsync(A.stats, 0, STATS_SLOTS * 8 * sizeof(unsigned long long), ctx->stream));
   HIP_TRY(ctx, hipEventRecord(ctx->ev0, ctx->stream));
   HIP_TRY(ctx, launch_by_mode(ctx, A, ctx->stream));
