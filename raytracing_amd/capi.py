@@ -9,7 +9,8 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_DIR = os.path.join(_HERE, "lib")
-LIBMRT_PATH = os.path.join(LIB_DIR, "libmrt.so")
+# MRT_LIB: an experimental build of the same library (make -C raytracing_amd/csrc variant ...), for tools/ only
+LIBMRT_PATH = os.environ.get("MRT_LIB") or os.path.join(LIB_DIR, "libmrt.so")
 LIBHOST_PATH = os.path.join(LIB_DIR, "libmrt_host.so")
 
 GEOM_SPHERE, GEOM_PLANE, GEOM_TRIANGLE = 0, 1, 2

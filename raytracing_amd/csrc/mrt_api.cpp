@@ -84,7 +84,7 @@ using namespace mrt::build;
 enum { STATIC_MAX_DIM = 16384, STATIC_MAX_DEVICES = 64 };
 enum : size_t {
   STATIC_STATS_BYTES = (size_t)STATS_SLOTS * 8 * sizeof(unsigned long long),
-  STATIC_UTAB_FLOATS = STATIC_MAX_DIM + 32, // whole tiles of up to 32 pixels
+  STATIC_UTAB_FLOATS = STATIC_MAX_DIM + 160, // mrt::uv_table_stride(STATIC_MAX_DIM)
   STATIC_SCRATCH_BYTES = STATIC_STATS_BYTES + (STATIC_UTAB_FLOATS + STATIC_MAX_DIM) * sizeof(float)
 };
 static __device__ __align__(256) unsigned char scratch[STATIC_SCRATCH_BYTES];
@@ -196,7 +196,7 @@ static hipError_t ensure_uv_tables(mrt_ctx *ctx, int W, int H, hipStream_t st, c
     for (auto &u : ctx->uv) (void)hipFree(u.mem);
     ctx->uv.clear();
   }
-  mrt_ctx::UvTables u{W, H, (W + 31) / 32 * 32, nullptr}; // whole tiles of up to 32 pixels
+  mrt_ctx::UvTables u{W, H, mrt::uv_table_stride(W), nullptr};
   try { ctx->uv.reserve(ctx->uv.size() + 1); } catch (...) { return hipErrorOutOfMemory; }
   if ((e = hipMalloc((void **)&u.mem, sizeof(float) * ((size_t)u.nu + H))) != hipSuccess) return e;
   if ((e = mrt::launch_uv_table(u.mem, u.nu, W, u.mem + u.nu, H, H, st)) != hipSuccess) { (void)hipFree(u.mem); return e; }
@@ -654,7 +654,7 @@ int mrt_render_device_static(mrt_ctx *ctx, const mrt_camera *cam, const mrt_rend
   hipStream_t st = (hipStream_t)stream;
   unsigned char *sp = (unsigned char *)ctx->static_scratch;
   unsigned long long *slots = (unsigned long long *)sp;
-  float *utab = (float *)(sp + STATIC_STATS_BYTES), *vtab = utab + STATIC_UTAB_FLOATS;
+  float *utab = (float *)(sp + STATIC_STATS_BYTES), *vtab = utab + mrt::uv_table_stride(A.W); // <= STATIC_UTAB_FLOATS
   HIP_TRY(ctx, order_after_last(ctx, st));
   if (stats_dev) { // the array keeps the last call's counts: clear them
     A.stats = slots;
@@ -664,8 +664,7 @@ int mrt_render_device_static(mrt_ctx *ctx, const mrt_camera *cam, const mrt_rend
   if ((long)A.sc.ns + A.sc.nt <= 64 && (ctx->cull == 1 || ctx->cull == 5)) {
     // the small-scene kernel's tables: rebuilt on every call, on the caller's stream (the array is shared by every
     // context on this GPU, so nothing is known about what the last call left in it)
-    const int nu = (A.W + 31) / 32 * 32;
-    HIP_TRY(ctx, mrt::launch_uv_table(utab, nu, A.W, vtab, A.H, A.H, st));
+    HIP_TRY(ctx, mrt::launch_uv_table(utab, mrt::uv_table_stride(A.W), A.W, vtab, A.H, A.H, st));
     A.utab = utab; A.vtab = vtab;
   }
   HIP_TRY(ctx, launch_by_mode(ctx, A, st));

@@ -125,6 +125,12 @@ static_assert(sizeof(SmallArgs) <= 4096, "kernel arguments are limited to 4 KB")
 // fills S for tiles of 8P x 8 pixels (mrt_small.hip): S.A = args with cone_ext set, S.prm
 void small_prepare_args(const RenderArgs &args, const SmallHost &host, int P, SmallArgs &S);
 hipError_t launch_uv_table(float *utab, int nu, int W, float *vtab, int nv, int H, hipStream_t stream);
+// floats between the start of the u table and the start of the v table behind it: whole tiles of up to 32 pixels,
+// plus room for the one-tile-ahead fetches of a wave's last tile (up to 4 tiles of 32 pixels per wave)
+#if defined(__HIPCC__)
+__host__ __device__
+#endif
+inline int uv_table_stride(int W) { return ((W + 31) & ~31) + 128; }
 
 // bounce chains, max_depth 1..8 (mrt_bounce.hip); a scene with a diffuse object needs args.rng; host != null
 // (scenes of at most 64 primitives) lets the primary rays use the small-scene kernel's per-tile culling

@@ -70,82 +70,184 @@ template <> struct VecOf<4> { using f = float4; using i = int4; using nf = nfloa
 
 __device__ __forceinline__ float abs1(float x, float y, float z) { return fabsf(x) + fabsf(y) + fabsf(z); }
 
+#ifndef MRT_TIMELINE
+#define TL_MARK(k) do { } while (0)
+#endif
+// Ablation builds (make variant DEFS=-DMRT_ABL=n; never the product library): bit 0 every tile takes the sky path,
+// bit 1 nothing is stored (the stores stay in the code behind a condition that is never true), bit 2 waves end
+// after the culling prologue, bit 3 approximate sqrt / division in the sky colour
+#ifndef MRT_ABL
+#define MRT_ABL 0
+#endif
+#ifdef MRT_TIMELINE
+// Diagnostic build only (tools/timeline.py): per wave, shader-clock stamps at entry, after the culling prologue,
+// before the stores and at exit, the 100 MHz real-time clock at entry, and where the wave ran.
+enum { TL_WORDS = 16, TL_MAX_WAVES = 1 << 16 };
+#define TL_MARK(k) do { if (tl_on && lane == 0) tlp[k] = __builtin_amdgcn_s_memtime(); } while (0)
+__device__ unsigned long long g_timeline[TL_WORDS * TL_MAX_WAVES];
+#endif
+
 // SmallArgs (mrt_internal.h): the common kernel arguments plus prm[field][lane], read straight from the argument
 // segment, one memory round trip after launch.
+//
+// SmallHot: what a wave needs before anything has arrived from memory.  These are the FIRST kernel arguments,
+// 14 dwords, and gfx950 loads them into SGPRs while it launches the wave (kernarg preload; Makefile:
+// -mllvm -amdgpu-kernarg-preload-count=14 for this file): the wave can issue the loads of its primitive's
+// parameters and of its u / v table entries, and compute its tiles' cones, in its first cycles instead of after a
+// scalar round trip (measured: the prologue was 3000 of a sky tile's 6200 cycles).  The camera is here in the form
+// the CULLING arithmetic uses (up_left - origin folded, approximate arithmetic is fine there); the rays are computed
+// from the exact twelve camera floats in SmallArgs, which have arrived by then.
+struct SmallHot {
+  float bx, by, bz;  // up_left - origin
+  float hx, hy, hz;  // horizontal
+  float vx, vy, vz;  // vertical
+  uint32_t wh;       // (W - 1) | (H - 1) << 16
+  float cone_ext;    // RenderArgs::cone_ext; negative: the frame is strip-partitioned (rows need the strip rule)
+  uint32_t meta;     // tiles per wave | ns << 8 | nt << 16
+  const float *utab; // u = col / W table; the v = row / H table follows at utab + uv_table_stride(W)
+};
+static_assert(sizeof(SmallHot) == 14 * 4, "the preloaded arguments are 14 dwords");
 
-template <int P, bool MULTI>
-__device__ __forceinline__ void render_small_body(const SmallArgs &S)
+template <int P, bool MULTI, int TPW>
+__device__ __forceinline__ void render_small_body(float qbx, float qby, float qbz, float qhx, float qhy, float qhz,
+                                                  float qvx, float qvy, float qvz, uint32_t wh, float cone_ext_s,
+                                                  uint32_t meta, const float *utab_hot, const SmallArgs &S)
 {
   const RenderArgs &A = S.A;
   const DevScene &sc = A.sc;
   const DevCamera &cam = A.cam;
-  const int lane = threadIdx.x & 63;
-  const int wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x; // one wave per workgroup
   const int tx = lane & 7, ty = lane >> 3;
-  const int ns = sc.ns, nt = sc.nt; // ns + nt <= 64 (launcher)
-  constexpr int TW = 8 * P;         // tile width in pixels
-
-  const int tile_x = blockIdx.x * (blockDim.x >> 6) + wave;
-  const int tile_y = blockIdx.y;
-  if (tile_x * TW >= A.W) return; // waves are independent: no barrier anywhere below
-  const int col0 = tile_x * TW + tx * P;
-  const int lrow = tile_y * 8 + ty;
-  const int lrow0 = tile_y * 8;
-  const int strip = lrow0 / A.strip_rows; // strips are multiples of 8 rows: a tile never straddles two
-  const int grow0 = (strip * A.nranks + A.rank) * A.strip_rows + (lrow0 - strip * A.strip_rows);
-  const int grow = grow0 + ty;
-  const bool valid_row = (lrow < A.local_rows) && (grow < A.H);
-
-  // ---- cone around the tile's rays, padded by one pixel on every side (covers the 121-spp offsets): every
-  //      ray of the padded tile is the centre ray plus an offset of norm <= cone_ext (launcher) ----
-  float cax, cay, caz, cosT, sinT;
-  const float rw = fast_rcp(float(A.W)), rh = fast_rcp(float(A.H)); // bound arithmetic: approximate is fine
-  const float um = (float(tile_x * TW) + 0.5f * float(TW - 1)) * rw, vm = (float(grow0) + 3.5f) * rh;
-  {
-    cax = ((cam.ux + um * cam.hx) + vm * cam.vx) - cam.ox;
-    cay = ((cam.uy + um * cam.hy) + vm * cam.vy) - cam.oy;
-    caz = ((cam.uz + um * cam.hz) + vm * cam.vz) - cam.oz;
-    const float inv = fast_rsq(dot3(cax, cay, caz, cax, cay, caz));
-    cax *= inv; cay *= inv; caz *= inv;
-    sinT = A.cone_ext * inv * (1.0f + 1e-4f) + 1e-6f;
-    cosT = fast_sqrt(fmaxf(1.0f - sinT * sinT, 0.0f)) * (1.0f - 1e-5f) - 1e-6f;
-    // a cone of 90 degrees or more (or a NaN camera) cannot cull: cos = -1 makes every ball pass
-    if (!(sinT < 0.99f) || !(cosT > 0.0f)) { cosT = -1.0f; sinT = 0.0f; }
+  constexpr int TW = 8 * P;     // tile width in pixels
+  // ---- from the preloaded arguments only: no memory access has returned yet ----
+  const int W = int(wh & 0xffffu) + 1, H = int(wh >> 16) + 1;
+  constexpr int tpw = TPW;      // tiles per wave
+  const int ns = int((meta >> 8) & 0xffu), nt = int((meta >> 16) & 0xffu); // ns + nt <= 64
+  const int tile_y = blockIdx.y, tile_x0 = blockIdx.x * tpw;
+  const int lrow0 = tile_y * 8, lrow = lrow0 + ty;
+#ifdef MRT_TIMELINE
+  const unsigned tl_idx = blockIdx.y * gridDim.x + blockIdx.x;
+  const bool tl_on = tl_idx < TL_MAX_WAVES;
+  unsigned long long *tlp = g_timeline + (size_t)TL_WORDS * (tl_on ? tl_idx : 0);
+  if (tl_on && lane == 0) {
+    tlp[0] = __builtin_amdgcn_s_memtime();
+    tlp[4] = __builtin_amdgcn_s_memrealtime();
+    tlp[5] = (unsigned long long)__builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11)) |               // HW_REG_HW_ID
+            ((unsigned long long)(__builtin_amdgcn_s_getreg(20 | (0 << 6) | (31 << 11)) & 0xF) << 32); // HW_REG_XCC_ID
   }
-
-  // ---- the primitive this lane owns: bound, and the ray-independent terms of the exact primary tests ----
+#endif
+  // the primitive this lane owns (spheres first, then triangles): culling parameters, straight from the argument
+  // segment (its address is in SGPRs from the start)
   const bool own_s = lane < ns, own_t = (lane >= ns) && (lane < ns + nt);
+  float cp[12];
+#pragma unroll
+  for (int i = 0; i < 12; ++i) cp[i] = 0.0f;
+  if (own_s) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) cp[i] = S.prm[i][lane];
+  } else if (own_t) {
+#pragma unroll
+    for (int i = 0; i < 12; ++i) cp[i] = S.prm[i][lane];
+  }
+  // rows: without a strip partition local row = frame row; with one, the strip rule (needs arguments from memory)
+  int grow0 = lrow0;
+  if (cone_ext_s < 0.0f) {
+    const int strip = lrow0 / A.strip_rows; // strips are multiples of 8 rows: a tile never straddles two
+    grow0 = (strip * A.nranks + A.rank) * A.strip_rows + (lrow0 - strip * A.strip_rows);
+  }
+  const int grow = grow0 + ty;
+  // u, v of the lane's pixels: tables hold float(i) / float(W) and float(i) / float(H) (uv_table_kernel); v is the
+  // same for all of the wave's tiles, u is fetched one tile ahead
+  const float *vtab_hot = utab_hot + uv_table_stride(W);
+  const float v = vtab_hot[grow < H ? grow : H - 1]; // rows beyond the frame are never written
+  using UV = typename VecOf<P>::f;
+
+  // ---- cones around the tiles' rays, each padded by one pixel on every side (covers the 121-spp offsets): every
+  //      ray of a padded tile is its centre ray plus an offset of norm <= cone_ext (launcher); which primitives
+  //      can any ray of tile j hit? ----
+  const float cone_ext = fabsf(cone_ext_s);
+  const float rw = fast_rcp(float(W)), rh = fast_rcp(float(H)); // bound arithmetic: approximate is fine
+  const float vm = (float(grow0) + 3.5f) * rh;
+  const float rbx = qbx + vm * qvx, rby = qby + vm * qvy, rbz = qbz + vm * qvz;
+  unsigned long long pmask[TPW];
+#pragma unroll
+  for (int j = 0; j < TPW; ++j) {
+    pmask[j] = 0ull;
+    { // wave-uniform
+      const float um = (float((tile_x0 + j) * TW) + 0.5f * float(TW - 1)) * rw;
+      bool pass = false;
+      if (own_s) {
+        float cax = rbx + um * qhx, cay = rby + um * qhy, caz = rbz + um * qhz;
+        const float inv = fast_rsq(dot3(cax, cay, caz, cax, cay, caz));
+        cax *= inv; cay *= inv; caz *= inv;
+        float sinT = cone_ext * inv * (1.0f + 1e-4f) + 1e-6f;
+        float cosT = fast_sqrt(fmaxf(1.0f - sinT * sinT, 0.0f)) * (1.0f - 1e-5f) - 1e-6f;
+        // a cone of 90 degrees or more (or a NaN camera) cannot cull: cos = -1 makes every ball pass
+        if (!(sinT < 0.99f) || !(cosT > 0.0f)) { cosT = -1.0f; sinT = 0.0f; }
+        pass = ball_may_touch_cone(cp[0], cp[1], cp[2], cp[3], cax, cay, caz, cosT, sinT);
+      } else if (own_t) {
+        bool cull = false;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const float f = __builtin_fmaf(um, cp[3 * i + 1], __builtin_fmaf(vm, cp[3 * i + 2], cp[3 * i]));
+          cull |= (f < 0.0f); // NaN compares false: never culls
+        }
+        pass = !cull;
+      }
+      pmask[j] = __ballot(pass);
+    }
+  }
+#ifdef MRT_TIMELINE
+  if (tl_on && lane == 0) {
+    tlp[1] = __builtin_amdgcn_s_memtime();
+    unsigned long long any = 0;
+    for (int j = 0; j < TPW; ++j) any |= pmask[j];
+    tlp[7] = any;
+  }
+#endif
+
+  // ---- the rest of what the lane keeps about its primitive: the ray-independent terms of the exact primary
+  //      tests, its bound and its centre / plane normal (shadow rays, hit records) ----
   float bx = 0.0f, by = 0.0f, bz = 0.0f, brad = 0.0f; // sphere centre + radius / triangle bound ball
   float g0 = 0.0f, g1 = 0.0f, g2 = 0.0f;               // sphere centre / triangle plane normal
   float e0 = 0.0f, e1 = 0.0f, e2 = 0.0f, e3 = 0.0f;    // sphere: o - c, |o - c|^2 - r^2;  triangle: e0 = k - n.o
   float rr = 0.0f;                                     // sphere: r^2
   int pobj = 0;
-  bool pass_primary = false;
   if (own_s) {
-    pass_primary = ball_may_touch_cone(S.prm[0][lane], S.prm[1][lane], S.prm[2][lane], S.prm[3][lane], cax, cay, caz,
-                                       cosT, sinT);
     e0 = S.prm[4][lane]; e1 = S.prm[5][lane]; e2 = S.prm[6][lane]; e3 = S.prm[7][lane];
     pobj = __float_as_int(S.prm[8][lane]);
-    // for the shadow rays and the hit record (not needed before the first exact test)
     bx = sc.sph_cx[lane]; by = sc.sph_cy[lane]; bz = sc.sph_cz[lane]; brad = sc.sph_r[lane];
     g0 = bx; g1 = by; g2 = bz;
     rr = brad * brad;
   } else if (own_t) {
     const int k = lane - ns;
-    bool cull = false;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const float f = __builtin_fmaf(um, S.prm[3 * i + 1][lane], __builtin_fmaf(vm, S.prm[3 * i + 2][lane], S.prm[3 * i][lane]));
-      cull |= (f < 0.0f); // NaN compares false: never culls
-    }
-    pass_primary = !cull;
     e0 = S.prm[12][lane];
     pobj = __float_as_int(S.prm[13][lane]);
     bx = sc.tri_bx[k]; by = sc.tri_by[k]; bz = sc.tri_bz[k]; brad = sc.tri_br[k];
     g0 = sc.tri[k]; g1 = sc.tri[nt + k]; g2 = sc.tri[2 * nt + k];
   }
   const unsigned long long smask_all = ns >= 64 ? ~0ull : ((1ull << ns) - 1ull);
-  const unsigned long long primary_mask = __ballot(pass_primary);
+  const bool valid_row = (lrow < A.local_rows) && (grow < A.H);
+  unsigned int n_shadow = 0, n_hit = 0, n_occl = 0, n_valid = 0;
+  unsigned int n_exact = 0, n_clusters = 0; // wave-uniform diagnostics (lane 0 reports them)
+  const int nsamp = MULTI ? A.spp : 1; // MULTI = false: one sample, no accumulation across samples
+  const float DIVW = 13.0f, DIVH = 13.0f;
+
+  // ================= one tile after the other =================
+  auto render_tile = [&](const int j) {
+  const int tile_x = tile_x0 + j;
+  if (tile_x * TW >= A.W) return;
+  unsigned long long primary_mask = pmask[0];
+#pragma unroll
+  for (int k = 1; k < TPW; ++k) primary_mask = j == k ? pmask[k] : primary_mask;
+  const int col0 = tile_x * TW + tx * P;
+  float u0[P];
+  {
+    const UV uu = *reinterpret_cast<const UV *>(utab_hot + col0); // the table is padded to whole tiles
+    const float *up = reinterpret_cast<const float *>(&uu);
+#pragma unroll
+    for (int p = 0; p < P; ++p) u0[p] = up[p];
+  }
 
   float accr[P], accg[P], accb[P];
   int out_id[P];
@@ -156,29 +258,52 @@ __device__ __forceinline__ void render_small_body(const SmallArgs &S)
     accr[p] = 0.0f; accg[p] = 0.0f; accb[p] = 0.0f;
     out_id[p] = -1; out_t[p] = MRT_INF;
     valid[p] = valid_row && (col0 + p < A.W);
+    n_valid += valid[p] ? 1u : 0u;
   }
-  unsigned int n_shadow = 0, n_hit = 0, n_occl = 0;
-  unsigned int n_exact = 0, n_clusters = 0; // wave-uniform diagnostics (lane 0 reports them)
-  const int nsamp = MULTI ? A.spp : 1; // MULTI = false: one sample, no accumulation across samples
-  const float DIVW = 13.0f, DIVH = 13.0f;
 
-  // u, v of the lane's pixels: tables hold float(i) / float(W) and float(i) / float(H) (uv_table_kernel)
-  float u0[P];
-  {
-    const typename VecOf<P>::f uu = *reinterpret_cast<const typename VecOf<P>::f *>(A.utab + col0);
-    const float *up = reinterpret_cast<const float *>(&uu);
-#pragma unroll
-    for (int p = 0; p < P; ++p) u0[p] = up[p];
-  }
-  const float v = A.vtab[grow < A.H ? grow : A.H - 1]; // rows beyond the frame are never written
-
-  for (int sidx = 0; sidx < nsamp; ++sidx) {
-    float offx = 0.0f, offy = 0.0f;
-    if (nsamp > 1) { // pipeline/multisample_mesh.cuh:23-30
+  // sky colour of a ray that hits nothing: src/main.cu:101-104
+  auto sky_colour = [](float nx, float ny, float nz, float &cr, float &cg, float &cb) {
+    if (MRT_ABL & 8) ny = ny * fast_rsq(dot3(nx, ny, nz, nx, ny, nz)); else
+    normalize3(nx, ny, nz);
+    const float y = 0.5f * (ny + 1.0f);
+    const float w0 = 1.0f - y;
+    cr = w0 * 1.0f + y * 0.5f; cg = w0 * 1.0f + y * 0.7f; cb = w0 * 1.0f + y * 1.0f;
+  };
+  // sub-pixel offset of sample sidx: pipeline/multisample_mesh.cuh:23-30
+  auto sample_offset = [&](int sidx, float &offx, float &offy) {
+    offx = 0.0f; offy = 0.0f;
+    if (nsamp > 1) {
       int r = sidx / 11, c = sidx - r * 11;
       offy = (-1.0f + 2.0f * float(r + 1) / DIVH) / float(A.H);
       offx = (-1.0f + 2.0f * float(c + 1) / DIVW) / float(A.W);
     }
+  };
+
+  if (MRT_ABL & 4) { if (W != 12345) return; }
+  if ((MRT_ABL & 1) || primary_mask == 0ull) {
+    // ---- no ray of this (padded) tile can hit a primitive: every sample is sky.  Same expressions as below for the
+    //      ray and the colour; none of the hit machinery, none of the lane's primitive data (75 % of the default
+    //      frame's pixels) ----
+    for (int sidx = 0; sidx < nsamp; ++sidx) {
+      float offx, offy;
+      sample_offset(sidx, offx, offy);
+      const float sv = nsamp > 1 ? v + offy : v;
+      n_clusters++;
+#pragma unroll
+      for (int p = 0; p < P; ++p) {
+        const float su = nsamp > 1 ? u0[p] + offx : u0[p];
+        const float dx = ((cam.ux + su * cam.hx) + sv * cam.vx) - cam.ox; // pipeline/viewport.cuh:30-34
+        const float dy = ((cam.uy + su * cam.hy) + sv * cam.vy) - cam.oy;
+        const float dz = ((cam.uz + su * cam.hz) + sv * cam.vz) - cam.oz;
+        float cr, cg, cb;
+        sky_colour(dx, dy, dz, cr, cg, cb);
+        accr[p] += cr; accg[p] += cg; accb[p] += cb; // src/main.cu:151
+      }
+    }
+  } else
+  for (int sidx = 0; sidx < nsamp; ++sidx) {
+    float offx, offy;
+    sample_offset(sidx, offx, offy);
     // ---- primary rays: pipeline/viewport.cuh:30-34 ----
     float dx[P], dy[P], dz[P], aa[P], best_t[P];
     int best_obj[P], best_k[P];
@@ -193,6 +318,7 @@ __device__ __forceinline__ void render_small_body(const SmallArgs &S)
       best_t[p] = MRT_INF; best_obj[p] = 0x7fffffff; best_k[p] = -1;
     }
 
+    TL_MARK(8); // rays set up
     // ---- closest hit over the surviving spheres: src/main.cu:60-77, core/sphere.cuh:32-73, [0.01, inf] ----
     {
       unsigned long long mask = primary_mask & smask_all;
@@ -247,6 +373,7 @@ __device__ __forceinline__ void render_small_body(const SmallArgs &S)
       }
     }
 
+    TL_MARK(9); // closest hits found
     // ---- hit records of the winners (core/sphere.cuh:45-47, core/triangle.cuh:96-97); the winner's centre /
     //      plane normal comes from the owning lane's registers ----
     bool have_hit[P], any_hit_lane = false;
@@ -278,6 +405,7 @@ __device__ __forceinline__ void render_small_body(const SmallArgs &S)
       }
     }
 
+    TL_MARK(10); // hit records
     // ---- shadow rays + direct light: core/light.cuh:135-178 ----
     float lr[P], lg[P], lb[P];
     bool have_light[P];
@@ -319,6 +447,7 @@ __device__ __forceinline__ void render_small_body(const SmallArgs &S)
 
       // One light.  POINT is a compile-time switch: for a directional light the shadow ray direction, its
       // squared length and the light's normal are wave-uniform scalars, for a point light per-pixel registers.
+      TL_MARK(11); // bundle
       auto shade_light = [&](auto point_tag, int li, float lvx, float lvy, float lvz) {
         constexpr bool POINT = decltype(point_tag)::value;
         constexpr int Q = POINT ? P : 1;
@@ -376,6 +505,7 @@ __device__ __forceinline__ void render_small_body(const SmallArgs &S)
             if (cull && sign_ok) pass = false;
           }
           const unsigned long long shadow_mask = __ballot(pass);
+          TL_MARK(12); // shadow candidates known (last light)
           n_clusters++; n_exact += __popcll(shadow_mask);
           unsigned long long mask = shadow_mask & smask_all;
           bool go = true;
@@ -422,6 +552,7 @@ __device__ __forceinline__ void render_small_body(const SmallArgs &S)
           }
         }
 
+        TL_MARK(13); // shadow rays traced (last light)
         const float lcr = sc.light_rgb[3 * li], lcg = sc.light_rgb[3 * li + 1], lcb = sc.light_rgb[3 * li + 2];
 #pragma unroll
         for (int p = 0; p < P; ++p) {
@@ -452,6 +583,7 @@ __device__ __forceinline__ void render_small_body(const SmallArgs &S)
       }
     }
 
+    TL_MARK(14); // lights done
     // ---- combine: src/main.cu:91-104 with MAX_RECURSION_DEPTH = 0 ----
 #pragma unroll
     for (int p = 0; p < P; ++p) {
@@ -463,11 +595,7 @@ __device__ __forceinline__ void render_small_body(const SmallArgs &S)
         if (have_light[p]) { cr = inc * mr + lr[p] * mr; cg = inc * mg + lg[p] * mg; cb = inc * mb + lb[p] * mb; }
         else { cr = inc * mr; cg = inc * mg; cb = inc * mb; }
       } else {
-        float nx = dx[p], ny = dy[p], nz = dz[p];
-        normalize3(nx, ny, nz);
-        const float y = 0.5f * (ny + 1.0f);
-        const float w0 = 1.0f - y;
-        cr = w0 * 1.0f + y * 0.5f; cg = w0 * 1.0f + y * 0.7f; cb = w0 * 1.0f + y * 1.0f;
+        sky_colour(dx[p], dy[p], dz[p], cr, cg, cb);
       }
       accr[p] += cr; accg[p] += cg; accb[p] += cb; // src/main.cu:151
       out_id[p] = have_hit[p] ? best_obj[p] : -1;
@@ -482,6 +610,10 @@ __device__ __forceinline__ void render_small_body(const SmallArgs &S)
     for (int p = 0; p < P; ++p) { accr[p] = accr[p] / fn; accg[p] = accg[p] / fn; accb[p] = accb[p] / fn; }
   }
   const size_t pix0 = size_t(A.frame_layout ? grow : lrow) * A.W + col0;
+#ifdef MRT_TIMELINE
+  if (tl_on && lane == 0) tlp[2] = __builtin_amdgcn_s_memtime();
+#endif
+  if ((MRT_ABL & 2) && accr[0] != 1234.5f) return;
   if (A.wide && valid_row && col0 + P <= A.W) {
     // the lane's 3P floats / P ints / P floats are contiguous and 4P-byte aligned (launcher checks W and pointers)
     using VF = typename VecOf<P>::f;
@@ -507,14 +639,21 @@ __device__ __forceinline__ void render_small_body(const SmallArgs &S)
         if (A.t) A.t[pix0 + p] = out_t[p];
       }
   }
+  }; // render_tile
+  if constexpr (TPW == 1) {
+    render_tile(0);
+  } else {
+#pragma unroll 1
+    for (int j = 0; j < TPW; ++j) render_tile(j);
+  }
 
+#ifdef MRT_TIMELINE
+  if (tl_on && lane == 0) { tlp[3] = __builtin_amdgcn_s_memtime(); tlp[6] = __builtin_amdgcn_s_memrealtime(); }
+#endif
   if (A.stats) {
     // counters are spread over stats_slots copies: same-address atomics cost ~12 ns each, one after the other
     unsigned long long *st = A.stats + 8u * ((blockIdx.x + 7u * blockIdx.y) & (unsigned)(A.stats_slots - 1));
-    unsigned int nvalid = 0;
-#pragma unroll
-    for (int p = 0; p < P; ++p) nvalid += valid[p] ? 1u : 0u;
-    unsigned int v4[4] = {nvalid * (unsigned)nsamp, n_shadow, n_hit, n_occl};
+    unsigned int v4[4] = {n_valid * (unsigned)nsamp, n_shadow, n_hit, n_occl};
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       unsigned int x = v4[k];
@@ -530,9 +669,19 @@ __device__ __forceinline__ void render_small_body(const SmallArgs &S)
 
 // Two pixels per lane and one sample fit 96 registers (five waves per SIMD) without spilling when asked to;
 // left alone the compiler takes 100 and loses a wave (measured: 23.2 -> 22.0 us on the default frame).
+#ifndef MRT_SMALL_WAVES
+#define MRT_SMALL_WAVES 5
+#endif
+#ifndef MRT_SMALL_TPW_DEFAULT
+#define MRT_SMALL_TPW_DEFAULT 1
+#endif
 template <int P, bool MULTI>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(P == 2 && !MULTI ? 5 : 1, 8)))
-void render_small_kernel(SmallArgs S) { render_small_body<P, MULTI>(S); }
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(P == 2 && !MULTI ? MRT_SMALL_WAVES : 1, 8)))
+void render_small_kernel(float qbx, float qby, float qbz, float qhx, float qhy, float qhz, float qvx, float qvy, float qvz,
+                         uint32_t wh, float cone_ext_s, uint32_t meta, const float *utab, SmallArgs S)
+{
+  render_small_body<P, MULTI, MRT_SMALL_TPW_DEFAULT>(qbx, qby, qbz, qhx, qhy, qhz, qvx, qvy, qvz, wh, cone_ext_s, meta, utab, S);
+}
 
 // ---- primary-ray functions (host, double; per render) ---------------------------------------------------
 // For triangle j (16 floats at tri16 + 16 j) and an accepted ray, sign(n.d) = sign(num) = s with
@@ -625,6 +774,11 @@ void small_prepare_args(const RenderArgs &in, const SmallHost &hs, int P, SmallA
   small_primary_functions(A, hs, hw * 1.0001, hh * 1.0001, dmax, S.prm);
 }
 
+// Tiles per wave: horizontally adjacent tiles can share one prologue (compile-time MRT_SMALL_TPW_DEFAULT).  Measured
+// on the default frame: more than one makes the frame SLOWER (2: +18 %, 4: +59 %) -- the waves of candidate tiles
+// live twice as long and the frame ends when the last of them does.
+static int small_tiles_per_wave() { return MRT_SMALL_TPW_DEFAULT; }
+
 template <int P>
 static hipError_t launch_small(const RenderArgs &in, const SmallHost &hs, hipStream_t stream)
 {
@@ -637,12 +791,23 @@ static hipError_t launch_small(const RenderArgs &in, const SmallHost &hs, hipStr
            ((uintptr_t)A.t & align) == 0;
   const int tiles_x = (A.W + 8 * P - 1) / (8 * P), tiles_y = (A.local_rows + 7) / 8;
   if (tiles_x == 0 || tiles_y == 0) return hipSuccess;
+  // the arguments the hardware preloads (SmallHot): camera in culling form, frame size, cone extent (its sign flags a
+  // strip partition), the u table, tiles per wave and primitive counts
+  const int tpw = small_tiles_per_wave();
+  const DevCamera &c = A.cam;
+  const bool partitioned = !(A.nranks == 1 && A.rank == 0);
+  const float cone_s = partitioned ? -A.cone_ext : A.cone_ext;
+  const uint32_t wh = (uint32_t)(A.W - 1) | ((uint32_t)(A.H - 1) << 16);
+  const uint32_t meta = (uint32_t)tpw | ((uint32_t)A.sc.ns << 8) | ((uint32_t)A.sc.nt << 16);
   // one wave per workgroup: waves share nothing, and single-wave workgroups fill freed wave slots sooner than
   // groups of four (measured 19.4 against 19.9 us on the default frame)
-  static const int wpw = getenv("MRT_SMALL_WPW") ? atoi(getenv("MRT_SMALL_WPW")) : 1;
-  const dim3 grid((tiles_x + wpw - 1) / wpw, tiles_y);
-  if (A.spp > 1) hipLaunchKernelGGL((render_small_kernel<P, true>), grid, dim3(64 * wpw), 0, stream, S);
-  else hipLaunchKernelGGL((render_small_kernel<P, false>), grid, dim3(64 * wpw), 0, stream, S);
+  const dim3 grid((tiles_x + tpw - 1) / tpw, tiles_y);
+  if (A.spp > 1)
+    hipLaunchKernelGGL((render_small_kernel<P, true>), grid, dim3(64), 0, stream, c.ux - c.ox, c.uy - c.oy, c.uz - c.oz,
+                       c.hx, c.hy, c.hz, c.vx, c.vy, c.vz, wh, cone_s, meta, A.utab, S);
+  else
+    hipLaunchKernelGGL((render_small_kernel<P, false>), grid, dim3(64), 0, stream, c.ux - c.ox, c.uy - c.oy, c.uz - c.oz,
+                       c.hx, c.hy, c.hz, c.vx, c.vy, c.vz, wh, cone_s, meta, A.utab, S);
   return hipGetLastError();
 }
 
@@ -659,9 +824,19 @@ static int small_pixels_per_lane(int spp)
   return forced ? forced : (spp > 1 ? 1 : 2);
 }
 
+#ifdef MRT_TIMELINE
+extern "C" int mrt_diag_timeline(unsigned long long *host_out, size_t words)
+{
+  return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_timeline), words * sizeof(unsigned long long), 0, hipMemcpyDeviceToHost);
+}
+#endif
+
 hipError_t launch_render_small(const RenderArgs &A, const SmallHost &hs, hipStream_t stream)
 {
-  if (A.sc.ns + A.sc.nt > 64 || !A.utab || !A.vtab || hs.ns != A.sc.ns || hs.nt != A.sc.nt) return hipErrorInvalidValue;
+  // the kernel finds the v table behind the u table (uv_table_stride) and packs the frame size into 2 x 16 bits
+  if (A.sc.ns + A.sc.nt > 64 || !A.utab || A.vtab != A.utab + uv_table_stride(A.W) || hs.ns != A.sc.ns ||
+      hs.nt != A.sc.nt || A.W > 65536 || A.H > 65536)
+    return hipErrorInvalidValue;
   switch (small_pixels_per_lane(A.spp)) {
   case 1: return launch_small<1>(A, hs, stream);
   case 4: return launch_small<4>(A, hs, stream);

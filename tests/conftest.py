@@ -3,6 +3,11 @@ import sys
 
 import pytest
 
+try:  # torch ships its own HIP runtime: load it before libmrt.so pulls in the system one, whatever tests are selected
+    import torch  # noqa: F401
+except ImportError:
+    pass
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (ROOT, os.path.join(ROOT, "tests")):
     if p not in sys.path:
