@@ -79,6 +79,16 @@ __device__ __forceinline__ float abs1(float x, float y, float z) { return fabsf(
 #ifndef MRT_ABL
 #define MRT_ABL 0
 #endif
+#ifndef MRT_SMALL_BANDS_LOG2
+#define MRT_SMALL_BANDS_LOG2 0 // 3: rows of tiles launched interleaved from 8 bands of the frame (measured: slower)
+#endif
+#ifndef MRT_SMALL_NT
+#define MRT_SMALL_NT 1 // frame stores are non-temporal
+#endif
+template <class T> __device__ __forceinline__ void frame_store(const T &x, T *p)
+{
+  if (MRT_SMALL_NT) __builtin_nontemporal_store(x, p); else *p = x;
+}
 #ifdef MRT_TIMELINE
 // Diagnostic build only (tools/timeline.py): per wave, shader-clock stamps at entry, after the culling prologue,
 // before the stores and at exit, the 100 MHz real-time clock at entry, and where the wave ran.
@@ -103,7 +113,7 @@ struct SmallHot {
   float vx, vy, vz;  // vertical
   uint32_t wh;       // (W - 1) | (H - 1) << 16
   float cone_ext;    // RenderArgs::cone_ext; negative: the frame is strip-partitioned (rows need the strip rule)
-  uint32_t meta;     // tiles per wave | ns << 8 | nt << 16
+  uint32_t meta;     // ns | nt << 8 | rows of tiles per band << 16 (row interleave, below)
   const float *utab; // u = col / W table; the v = row / H table follows at utab + uv_table_stride(W)
 };
 static_assert(sizeof(SmallHot) == 14 * 4, "the preloaded arguments are 14 dwords");
@@ -122,9 +132,18 @@ __device__ __forceinline__ void render_small_body(float qbx, float qby, float qb
   // ---- from the preloaded arguments only: no memory access has returned yet ----
   const int W = int(wh & 0xffffu) + 1, H = int(wh >> 16) + 1;
   constexpr int tpw = TPW;      // tiles per wave
-  const int ns = int((meta >> 8) & 0xffu), nt = int((meta >> 16) & 0xffu); // ns + nt <= 64
-  const int tile_y = blockIdx.y, tile_x0 = blockIdx.x * tpw;
+  const int ns = int(meta & 0xffu), nt = int((meta >> 8) & 0xffu); // ns + nt <= 64
+  // Experiment knob (MRT_SMALL_BANDS_LOG2 > 0, default 0 = row order): the grid's row y becomes row
+  // (y % BANDS) * band_rows + y / BANDS of the frame, so consecutive workgroups come from BANDS places spread over its
+  // height and sky tiles (bound by the stores) run beside hit tiles (bound by instruction issue).  Measured on the
+  // default frame: SLOWER, 17.8 -> 20.1 us with 2 or 8 bands (gpurun_out/exp_bands_*.txt), as is raising the priority
+  // of hit waves (19.9 us): vector loads of a hit wave queue behind the stores of the sky waves that share its CU.
+  constexpr int BANDS = 1 << MRT_SMALL_BANDS_LOG2;
+  const int band_rows = int(meta >> 16);
+  const int tile_y = int(blockIdx.y & (BANDS - 1)) * band_rows + int(blockIdx.y >> MRT_SMALL_BANDS_LOG2);
+  const int tile_x0 = blockIdx.x * tpw;
   const int lrow0 = tile_y * 8, lrow = lrow0 + ty;
+  if (lrow0 >= H) return; // the grid is padded to BANDS * band_rows rows (and no rank has more rows than the frame)
 #ifdef MRT_TIMELINE
   const unsigned tl_idx = blockIdx.y * gridDim.x + blockIdx.x;
   const bool tl_on = tl_idx < TL_MAX_WAVES;
@@ -152,6 +171,7 @@ __device__ __forceinline__ void render_small_body(float qbx, float qby, float qb
   // rows: without a strip partition local row = frame row; with one, the strip rule (needs arguments from memory)
   int grow0 = lrow0;
   if (cone_ext_s < 0.0f) {
+    if (lrow0 >= A.local_rows) return;
     const int strip = lrow0 / A.strip_rows; // strips are multiples of 8 rows: a tile never straddles two
     grow0 = (strip * A.nranks + A.rank) * A.strip_rows + (lrow0 - strip * A.strip_rows);
   }
@@ -300,7 +320,7 @@ __device__ __forceinline__ void render_small_body(float qbx, float qby, float qb
         accr[p] += cr; accg[p] += cg; accb[p] += cb; // src/main.cu:151
       }
     }
-  } else
+  } else {
   for (int sidx = 0; sidx < nsamp; ++sidx) {
     float offx, offy;
     sample_offset(sidx, offx, offy);
@@ -602,6 +622,7 @@ __device__ __forceinline__ void render_small_body(float qbx, float qby, float qb
       out_t[p] = best_t[p];
     }
   }
+  }
 
   // ---- framebuffer: src/main.cu:155 (x / 1.0f == x, so the division is skipped for one sample) ----
   if (nsamp > 1) {
@@ -625,9 +646,9 @@ __device__ __forceinline__ void render_small_body(float qbx, float qby, float qb
     using NF = typename VecOf<P>::nf;
     using NI = typename VecOf<P>::ni;
 #pragma unroll
-    for (int k = 0; k < 3; ++k) __builtin_nontemporal_store(*reinterpret_cast<const NF *>(&o[P * k]), reinterpret_cast<NF *>(dst) + k);
-    if (A.id) __builtin_nontemporal_store(*reinterpret_cast<const NI *>(&out_id[0]), reinterpret_cast<NI *>(A.id + pix0));
-    if (A.t) __builtin_nontemporal_store(*reinterpret_cast<const NF *>(&out_t[0]), reinterpret_cast<NF *>(A.t + pix0));
+    for (int k = 0; k < 3; ++k) frame_store(*reinterpret_cast<const NF *>(&o[P * k]), reinterpret_cast<NF *>(dst) + k);
+    if (A.id) frame_store(*reinterpret_cast<const NI *>(&out_id[0]), reinterpret_cast<NI *>(A.id + pix0));
+    if (A.t) frame_store(*reinterpret_cast<const NF *>(&out_t[0]), reinterpret_cast<NF *>(A.t + pix0));
   } else {
 #pragma unroll
     for (int p = 0; p < P; ++p)
@@ -798,10 +819,12 @@ static hipError_t launch_small(const RenderArgs &in, const SmallHost &hs, hipStr
   const bool partitioned = !(A.nranks == 1 && A.rank == 0);
   const float cone_s = partitioned ? -A.cone_ext : A.cone_ext;
   const uint32_t wh = (uint32_t)(A.W - 1) | ((uint32_t)(A.H - 1) << 16);
-  const uint32_t meta = (uint32_t)tpw | ((uint32_t)A.sc.ns << 8) | ((uint32_t)A.sc.nt << 16);
+  constexpr int BANDS = 1 << MRT_SMALL_BANDS_LOG2;
+  const int band_rows = (tiles_y + BANDS - 1) / BANDS; // < 65536: tiles_y <= 8192
+  const uint32_t meta = (uint32_t)A.sc.ns | ((uint32_t)A.sc.nt << 8) | ((uint32_t)band_rows << 16);
   // one wave per workgroup: waves share nothing, and single-wave workgroups fill freed wave slots sooner than
   // groups of four (measured 19.4 against 19.9 us on the default frame)
-  const dim3 grid((tiles_x + tpw - 1) / tpw, tiles_y);
+  const dim3 grid((tiles_x + tpw - 1) / tpw, band_rows * BANDS);
   if (A.spp > 1)
     hipLaunchKernelGGL((render_small_kernel<P, true>), grid, dim3(64), 0, stream, c.ux - c.ox, c.uy - c.oy, c.uz - c.oz,
                        c.hx, c.hy, c.hz, c.vx, c.vy, c.vz, wh, cone_s, meta, A.utab, S);

@@ -1,0 +1,97 @@
+// ubench_launch.hip -- what a frame-sized grid costs before it computes anything (diagnostic, not part of the library).
+//   hipcc --offload-arch=gfx950 -O3 -o /tmp/ubench_launch tools/ubench_launch.hip && /tmp/ubench_launch
+// Cases: empty kernels of 16200 / 8100 / 4050 workgroups of 1 / 2 / 4 waves; the same with a 4 KB argument block;
+// kernels that only write a 1920x1080 frame of 20 B per pixel (12 + 4 + 4, like the render kernels) with different
+// pixels per wave, plain and non-temporal stores.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); exit(1); } } while (0)
+
+struct Big { float f[960]; };
+
+__global__ void empty_kernel(int *p) { if (p && threadIdx.x == 12345) *p = 1; }
+__global__ void empty_big_kernel(Big b, int *p) { if (p && threadIdx.x == 12345) *p = (int)b.f[5]; }
+
+typedef float nfloat2 __attribute__((ext_vector_type(2)));
+typedef float nfloat4 __attribute__((ext_vector_type(4)));
+
+// a wave writes a tile of (8 * P * T) x 8 pixels: lane (tx, ty) owns P adjacent pixels in each of T tiles side by side
+template <int P, bool NT>
+__global__ __launch_bounds__(256) void store_kernel(float *rgb, int *id, float *t, int W, int H, int T)
+{
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int tx = lane & 7, ty = lane >> 3;
+  const int row = blockIdx.y * 8 + ty;
+  if (row >= H) return;
+  for (int j = 0; j < T; ++j) {
+    const int col0 = ((blockIdx.x * (blockDim.x >> 6) + wave) * T + j) * 8 * P + tx * P;
+    if (col0 + P > W) return;
+    const size_t pix = (size_t)row * W + col0;
+    float v = (float)(row + col0) * 1e-6f;
+    if constexpr (P == 2) {
+      nfloat2 a = {v, v + 1.f}, b = {v + 2.f, v}, c = {v + 1.f, v + 2.f};
+      nfloat2 *d = reinterpret_cast<nfloat2 *>(rgb + 3 * pix);
+      if (NT) { __builtin_nontemporal_store(a, d); __builtin_nontemporal_store(b, d + 1); __builtin_nontemporal_store(c, d + 2);
+                __builtin_nontemporal_store(a, reinterpret_cast<nfloat2 *>(id + pix)); __builtin_nontemporal_store(b, reinterpret_cast<nfloat2 *>(t + pix)); }
+      else { d[0] = a; d[1] = b; d[2] = c; *reinterpret_cast<nfloat2 *>(id + pix) = a; *reinterpret_cast<nfloat2 *>(t + pix) = b; }
+    } else if constexpr (P == 4) {
+      nfloat4 a = {v, v + 1.f, v + 2.f, v};
+      nfloat4 *d = reinterpret_cast<nfloat4 *>(rgb + 3 * pix);
+      if (NT) { __builtin_nontemporal_store(a, d); __builtin_nontemporal_store(a, d + 1); __builtin_nontemporal_store(a, d + 2);
+                __builtin_nontemporal_store(a, reinterpret_cast<nfloat4 *>(id + pix)); __builtin_nontemporal_store(a, reinterpret_cast<nfloat4 *>(t + pix)); }
+      else { d[0] = a; d[1] = a; d[2] = a; *reinterpret_cast<nfloat4 *>(id + pix) = a; *reinterpret_cast<nfloat4 *>(t + pix) = a; }
+    } else {
+      if (NT) { __builtin_nontemporal_store(v, rgb + 3 * pix); __builtin_nontemporal_store(v, rgb + 3 * pix + 1); __builtin_nontemporal_store(v, rgb + 3 * pix + 2);
+                __builtin_nontemporal_store(v, reinterpret_cast<float *>(id + pix)); __builtin_nontemporal_store(v, t + pix); }
+      else { rgb[3 * pix] = v; rgb[3 * pix + 1] = v; rgb[3 * pix + 2] = v; id[pix] = (int)v; t[pix] = v; }
+    }
+  }
+}
+
+template <class F> static float time_us(F launch, int n = 400)
+{
+  hipEvent_t e0, e1;
+  CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  float best = 1e30f;
+  for (int rep = 0; rep < 3; ++rep) {
+    for (int i = 0; i < 20; ++i) launch();
+    CK(hipDeviceSynchronize());
+    CK(hipEventRecord(e0, 0));
+    for (int i = 0; i < n; ++i) launch();
+    CK(hipEventRecord(e1, 0));
+    CK(hipEventSynchronize(e1));
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+    best = ms * 1000.f / n < best ? ms * 1000.f / n : best;
+  }
+  return best;
+}
+
+int main()
+{
+  const int W = 1920, H = 1080;
+  float *rgb, *t; int *id;
+  CK(hipMalloc(&rgb, (size_t)W * H * 12)); CK(hipMalloc(&id, (size_t)W * H * 4)); CK(hipMalloc(&t, (size_t)W * H * 4));
+  Big big; for (int i = 0; i < 960; ++i) big.f[i] = (float)i;
+  printf("empty kernels, total waves 16200 (120 x 135 tiles):\n");
+  for (int wpw : {1, 2, 4}) {
+    dim3 g(120 / wpw, 135);
+    printf("  %d wave(s) per workgroup, %5d workgroups: %.2f us;  with 3.8 KB of arguments: %.2f us\n", wpw, g.x * g.y,
+           time_us([&] { hipLaunchKernelGGL(empty_kernel, g, dim3(64 * wpw), 0, 0, (int *)nullptr); }),
+           time_us([&] { hipLaunchKernelGGL(empty_big_kernel, g, dim3(64 * wpw), 0, 0, big, (int *)nullptr); }));
+  }
+  printf("empty kernels, 1 wave per workgroup, by grid size:\n");
+  for (int n : {1, 256, 1024, 2048, 4096, 8192, 16384, 32768, 65536})
+    printf("  %6d workgroups: %.2f us\n", n, time_us([&] { hipLaunchKernelGGL(empty_kernel, dim3(n), dim3(64), 0, 0, (int *)nullptr); }));
+  printf("store-only kernels (41.5 MB per launch):\n");
+#define CASE(P, NT, WPW, T) { dim3 g((W / (8 * P * T) + WPW - 1) / WPW, 135); \
+    float us = time_us([&] { hipLaunchKernelGGL((store_kernel<P, NT>), g, dim3(64 * WPW), 0, 0, rgb, id, t, W, H, T); }); \
+    printf("  P=%d tiles/wave=%d waves/wg=%d nt=%d (%5d waves): %.2f us = %.0f GB/s\n", P, T, WPW, (int)NT, g.x * g.y * WPW, us, W * H * 20.0 / us * 1e-3); }
+  CASE(1, false, 1, 1) CASE(1, true, 1, 1) CASE(1, true, 4, 1)
+  CASE(2, false, 1, 1) CASE(2, true, 1, 1) CASE(2, true, 2, 1) CASE(2, true, 4, 1)
+  CASE(2, true, 1, 2) CASE(2, true, 1, 4)
+  CASE(4, false, 1, 1) CASE(4, true, 1, 1) CASE(4, true, 4, 1) CASE(4, true, 1, 2) CASE(4, true, 1, 4)
+  return 0;
+}
