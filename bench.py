@@ -225,6 +225,35 @@ def main():
     fr = multigpu.FrameRenderer(flat, cam12, W, H, rank=rank, num_ranks=world, device=local_rank, spp=spp,
                                 max_depth=max_depth)
     fr.ctx.set_cull(0 if args.brute_force else 1)
+    # The exchange step's carrier: mrt_gather_strips (RCCL behind the C-ABI) on a communicator made from an id that
+    # rank 0 creates and torch.distributed hands round.  If any rank cannot create it (or MRT_BENCH_GATHER=torch, or a
+    # gloo rehearsal with ranks sharing a GPU) every rank uses torch.distributed's point-to-point calls instead.
+    gather = "none"
+    if world > 1:
+        gather = "torch.distributed point-to-point (" + backend + ")"
+        if backend == "nccl" and os.environ.get("MRT_BENCH_GATHER", "capi") == "capi":
+            from raytracing_amd import capi
+            uid = [None]
+            ok = 1
+            try:
+                if rank == 0:
+                    uid[0] = capi.comm_unique_id()
+            except capi.MrtError as e:
+                progress(f"mrt_comm_unique_id failed: {e}")
+            dist.broadcast_object_list(uid, src=0)
+            try:
+                if uid[0] is None:
+                    raise capi.MrtError("no communicator id")
+                fr.init_comm(uid[0])
+            except capi.MrtError as e:
+                ok = 0
+                print(f"[bench] rank {rank}: mrt_comm_create failed: {e}", file=sys.stderr, flush=True)
+            flag = torch.tensor([ok], dtype=torch.int32, device=fr.dev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if int(flag.item()) == 1:
+                gather = "mrt_gather_strips (RCCL behind the C-ABI: ncclSend per peer, grouped ncclRecv on rank 0)"
+            else:
+                fr.drop_comm()
     bytes_pp = BYTES_PER_PIXEL
     if max_depth > 0:
         bytes_pp += 20  # the pixel's random stream: five xorshift words read per frame (mrt_rng.hip)
@@ -324,8 +353,8 @@ def main():
             "config": {"workload": f"{args.config}: {label}", "width": W, "height": H, "spp": spp, "max_depth": max_depth,
                        "primary_rays": primary, "shadow_rays": shadow,
                        "parallelism": f"{world} GPU(s): strips of {fr.strip_rows} rows round-robin, scene replicated" +
-                                      ("" if world == 1 else ", one RCCL message per peer to rank 0 (rgb + id + t), "
-                                                             "rank 0 renders in place and scatters the rest"),
+                                      ("" if world == 1 else ", one message per peer to rank 0 (rgb + id + t), "
+                                                             "rank 0 renders in place and scatters the rest; carrier: " + gather),
                        "outputs": "rgb f32 + id i32 + t f32" + ("" if world == 1 else ", all three gathered on rank 0"),
                        "kernel": kernel_desc},
             "roofline": {"bound": "hbm", "achieved": round(ach_gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",

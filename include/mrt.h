@@ -11,8 +11,9 @@
  *  - every function returns MRT_OK (0) or a negative mrt_status; nothing exits
  *    or throws (the fail-fast print-and-exit convention of src/check_error.cu:7-15
  *    lives on the C++ side as checkRtErrors(), raytracing_amd/host/hip_utils/check_error.hpp);
- *  - one context drives ONE GPU (one process per GPU; multi-GPU frames are split
- *    in strips by the caller, see mrt_partition);
+ *  - one context drives ONE GPU; multi-GPU frames are split in strips (mrt_partition)
+ *    and gathered on rank 0 over RCCL (mrt_comm_*, mrt_gather_strips, mrt_render_multi),
+ *    one process per GPU or one process over several contexts;
  *  - calls on one context are serialised by the caller (the reference is single
  *    threaded, src/main.cu:159-260).  Renders of one context share its counters and
  *    scratch, so the library orders them on the GPU: a render enqueued on another
@@ -221,6 +222,54 @@ int mrt_render_device_static(mrt_ctx *ctx, const mrt_camera *cam, const mrt_rend
 int mrt_scatter_strips(mrt_ctx *ctx, const void *staging_dev, void *frame_rgb_dev, void *frame_id_dev,
                        void *frame_t_dev, int32_t width, int32_t height, int32_t num_ranks, int32_t strip_rows,
                        int32_t skip_rank, void *stream);
+
+/*
+ * --- multi-GPU frames over RCCL, behind the C-ABI (no reference counterpart: the reference is single GPU and has
+ * no collective call).  The library opens RCCL (librccl.so.1) at the first mrt_comm_* call; a process
+ * that never makes one does not load it.  Two ways to use N GPUs:
+ *   one process per GPU   mrt_comm_unique_id on rank 0, the 128 bytes handed to every rank by whatever the caller
+ *                         has (a file, a socket, MPI, torch.distributed), then mrt_comm_create on every rank;
+ *   one process, N GPUs   mrt_comm_create_local over N contexts (ncclCommInitAll); mrt_render_multi does the rest.
+ * A communicator belongs to the context it was created with.  mrt_comm_destroy(NULL) is a no-op.
+ */
+typedef struct mrt_comm mrt_comm;
+enum { MRT_COMM_ID_BYTES = 128 };
+int mrt_comm_unique_id(uint8_t id[MRT_COMM_ID_BYTES]);
+/* collective over the num_ranks callers: every rank calls it with the same id */
+int mrt_comm_create(mrt_ctx *ctx, const uint8_t id[MRT_COMM_ID_BYTES], int32_t rank, int32_t num_ranks, mrt_comm **out);
+/* one process: out[i] is the communicator of ctxs[i], rank i of n (the contexts must sit on n different GPUs) */
+int mrt_comm_create_local(mrt_ctx *const *ctxs, int32_t n, mrt_comm **out);
+int mrt_comm_destroy(mrt_comm *comm);
+
+/*
+ * The one exchange step of a multi-GPU frame, asynchronous on `stream` (a stream of ctx's GPU).  Every rank calls it
+ * once per frame with the frame's width, height and strip_rows -- each rank from its own process or thread: RCCL
+ * connects two ranks when both have posted, so one thread cannot post for several ranks one after the other
+ * (mrt_render_multi is the single-thread form).
+ *   rank != 0: sends packed_dev -- its local rows back to back as three planes, rgb [rows*W*3] | id [rows*W] |
+ *              t [rows*W], what mrt_render_device leaves with frame_layout 0 in one buffer -- to rank 0 (ncclSend, one
+ *              message over the rank's own xGMI link); the other pointers are ignored;
+ *   rank 0:    receives every peer's buffer into staging_dev (rank order, one grouped batch of ncclRecv) and then
+ *              copies the strips to their places in the three H x W frame planes (mrt_scatter_strips on the same
+ *              stream).  With root_in_place != 0 rank 0 has rendered its own strips straight into the frame
+ *              (frame_layout 1) and packed_dev is ignored; with 0 its own packed buffer travels like everybody
+ *              else's (a send to itself), which is also how the path can be exercised on a single GPU.
+ * staging_dev holds 5 dwords per pixel of every rank that sends.
+ */
+int mrt_gather_strips(mrt_ctx *ctx, mrt_comm *comm, const void *packed_dev, void *staging_dev, void *frame_rgb_dev,
+                      void *frame_id_dev, void *frame_t_dev, int32_t width, int32_t height, int32_t strip_rows,
+                      int32_t root_in_place, void *stream);
+
+/*
+ * One process, n GPUs, blocking, HOST buffers: the multi-GPU form of mrt_render.  ctxs[i] renders the strips of rank
+ * i (params->part.strip_rows rows each, dealt round robin; part.rank / num_ranks / frame_layout are ignored), rank 0
+ * in place, the others into packed buffers that mrt_gather_strips brings to ctxs[0]; the whole frame is then copied
+ * to rgb [H*W*3], id [H*W], t [H*W] (id / t / stats may be NULL).  Every context must hold the same scene.
+ * comms = what mrt_comm_create_local returned for ctxs (may be NULL when n == 1).  stats: sums over the ranks,
+ * kernel_ms = the slowest rank's render kernel.  The result is bit-identical to mrt_render on one GPU.
+ */
+int mrt_render_multi(mrt_ctx *const *ctxs, mrt_comm *const *comms, int32_t n, const mrt_camera *cam,
+                     const mrt_render_params *params, float *rgb, int32_t *id, float *t, mrt_stats *stats);
 
 /*
  * Batched single-primitive intersection on the GPU: replaces the test kernels

@@ -21,7 +21,8 @@ LIGHT_DIRECTIONAL, LIGHT_POINT = 0, 1
 MRT_SYMBOLS = [
     "mrt_device_count", "mrt_ctx_create", "mrt_ctx_destroy", "mrt_ctx_set_option", "mrt_last_error", "mrt_status_string",
     "mrt_triangle_bound", "mrt_rng_state", "mrt_host_alloc", "mrt_host_free", "mrt_scene_upload", "mrt_local_rows", "mrt_render", "mrt_render_device", "mrt_render_device_static", "mrt_scatter_strips",
-    "mrt_intersect",
+    "mrt_intersect", "mrt_comm_unique_id", "mrt_comm_create", "mrt_comm_create_local", "mrt_comm_destroy",
+    "mrt_gather_strips", "mrt_render_multi",
 ]
 
 _f = C.POINTER(C.c_float)
@@ -112,6 +113,13 @@ def libmrt():
         L.mrt_scatter_strips.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,
                                          C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]
         L.mrt_intersect.argtypes = [C.c_void_p, C.c_int, _f, _f, C.c_float, C.c_float, C.c_int64, _u8, _f, _f, _f]
+        L.mrt_comm_unique_id.argtypes = [C.c_void_p]
+        L.mrt_comm_create.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.POINTER(C.c_void_p)]
+        L.mrt_comm_create_local.argtypes = [C.POINTER(C.c_void_p), C.c_int32, C.POINTER(C.c_void_p)]
+        L.mrt_comm_destroy.argtypes = [C.c_void_p]
+        L.mrt_gather_strips.argtypes = [C.c_void_p] * 7 + [C.c_int32] * 4 + [C.c_void_p]
+        L.mrt_render_multi.argtypes = [C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_int32, C.POINTER(Camera),
+                                       C.POINTER(RenderParams), C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(Stats)]
         _libmrt = L
     return _libmrt
 
@@ -452,6 +460,15 @@ class Context:
                                         W, H, num_ranks, strip_rows, skip_rank, C.c_void_p(stream) if stream else None)
         self._check(rc, "mrt_scatter_strips")
 
+    def gather_strips(self, comm, packed_ptr, staging_ptr, rgb_ptr, id_ptr, t_ptr, W, H, strip_rows=8, root_in_place=True,
+                      stream=None):
+        """The exchange step of a multi-GPU frame over RCCL (mrt_gather_strips): ranks other than 0 send their packed
+        buffer, rank 0 receives them all and puts the strips in place.  Asynchronous on `stream`."""
+        v = lambda p: C.c_void_p(p) if p else None
+        rc = self._L.mrt_gather_strips(self._h, comm._h, v(packed_ptr), v(staging_ptr), v(rgb_ptr), v(id_ptr), v(t_ptr),
+                                       W, H, strip_rows, 1 if root_in_place else 0, v(stream))
+        self._check(rc, "mrt_gather_strips")
+
     def intersect(self, prim_kind, prim, rays, tmin, tmax):
         """Batched hit test of one primitive against rays [n,6] (origin, direction)."""
         prim = np.ascontiguousarray(prim, dtype=np.float32).reshape(-1)
@@ -465,3 +482,63 @@ class Context:
                                    hit.ctypes.data_as(_u8), _fp(t), _fp(point), _fp(normal))
         self._check(rc, "mrt_intersect")
         return hit.astype(bool), t, point, normal
+
+
+def comm_unique_id():
+    """128 bytes that name a new communicator (ncclGetUniqueId): made on rank 0, handed to every rank by the caller."""
+    L = libmrt()
+    buf = (C.c_uint8 * 128)()
+    rc = L.mrt_comm_unique_id(buf)
+    if rc != 0:
+        raise MrtError(f"mrt_comm_unique_id: {rc} {L.mrt_last_error(None).decode()}")
+    return bytes(buf)
+
+
+class Comm:
+    """One rank's RCCL communicator (mrt_comm), tied to a Context."""
+
+    def __init__(self, ctx, unique_id, rank, num_ranks):
+        self._L, self.ctx, self.rank, self.num_ranks = ctx._L, ctx, rank, num_ranks
+        h = C.c_void_p()
+        buf = (C.c_uint8 * 128).from_buffer_copy(unique_id)
+        ctx._check(self._L.mrt_comm_create(ctx._h, buf, rank, num_ranks, C.byref(h)), "mrt_comm_create")
+        self._h = h
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.mrt_comm_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def render_multi(ctxs, cam12, W, H, spp=1, max_depth=0, strip_rows=8, comms=None, want_stats=True):
+    """One process, len(ctxs) GPUs (mrt_render_multi): blocking render of the whole frame into host arrays.  comms:
+    raw handles from mrt_comm_create_local, created here (and destroyed) when None and more than one context."""
+    L = libmrt()
+    n = len(ctxs)
+    hs = (C.c_void_p * n)(*[c._h for c in ctxs])
+    own = None
+    if comms is None and n > 1:
+        own = (C.c_void_p * n)()
+        ctxs[0]._check(L.mrt_comm_create_local(hs, n, own), "mrt_comm_create_local")
+        comms = own
+    rgb = np.zeros((H, W, 3), dtype=np.float32)
+    ids = np.full((H, W), -2, dtype=np.int32)
+    t = np.zeros((H, W), dtype=np.float32)
+    cam = Camera.from12(cam12)
+    p = Context._params(W, H, spp, max_depth, 0, 1, strip_rows)
+    st = Stats()
+    try:
+        rc = L.mrt_render_multi(hs, comms, n, C.byref(cam), C.byref(p), rgb.ctypes.data, ids.ctypes.data, t.ctypes.data,
+                                C.byref(st) if want_stats else None)
+        ctxs[0]._check(rc, "mrt_render_multi")
+    finally:
+        if own is not None:
+            for h in own:
+                L.mrt_comm_destroy(h)
+    return {"rgb": rgb, "id": ids, "t": t, "stats": st.as_dict() if want_stats else None}

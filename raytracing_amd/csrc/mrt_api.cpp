@@ -10,11 +10,15 @@
 #include "mrt_internal.h"
 #include "mrt_scene_build.h"
 
+#include <dlfcn.h>
+#include <rccl/rccl.h> // types and prototypes only: the library is opened at the first mrt_comm_* call
+
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <algorithm>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <string>
 #include <vector>
@@ -787,6 +791,323 @@ int mrt_intersect(mrt_ctx *ctx, int prim_kind, const float *prim, const float *r
   if (e != hipSuccess) rc = hip_fail(ctx, e, "mrt_intersect");
   (void)hipFree(mem);
   return rc;
+}
+
+} // extern "C"
+
+// ---- multi-GPU: RCCL behind the C-ABI (include/mrt.h; no reference counterpart) ----------------------
+// RCCL is opened on first use, by soname: a process that has loaded a librccl.so.1 already (torch ships one) gets
+// that one, everybody else the one of the ROCm installation.  libmrt.so itself does not depend on it.
+namespace {
+struct Rccl {
+  void *lib = nullptr;
+  std::string err;
+  decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+  decltype(&ncclCommInitRank) CommInitRank = nullptr;
+  decltype(&ncclCommInitAll) CommInitAll = nullptr;
+  decltype(&ncclCommDestroy) CommDestroy = nullptr;
+  decltype(&ncclSend) Send = nullptr;
+  decltype(&ncclRecv) Recv = nullptr;
+  decltype(&ncclGroupStart) GroupStart = nullptr;
+  decltype(&ncclGroupEnd) GroupEnd = nullptr;
+  decltype(&ncclGetErrorString) GetErrorString = nullptr;
+};
+
+const Rccl *rccl(std::string *why)
+{
+  static Rccl R;
+  static std::once_flag once;
+  std::call_once(once, [] {
+    const char *env = getenv("MRT_RCCL_LIB");
+    const char *names[] = {env, "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    for (const char *n : names) {
+      if (!n || !*n) continue;
+      R.lib = dlopen(n, RTLD_NOW | RTLD_LOCAL);
+      if (R.lib) break;
+      R.err = dlerror();
+    }
+    if (!R.lib) { R.err = "cannot open RCCL (librccl.so.1): " + R.err; return; }
+    bool ok = true;
+    auto sym = [&](const char *name) { void *f = dlsym(R.lib, name); if (!f) { ok = false; R.err = std::string("RCCL lacks ") + name; } return f; };
+    R.GetUniqueId = (decltype(R.GetUniqueId))sym("ncclGetUniqueId");
+    R.CommInitRank = (decltype(R.CommInitRank))sym("ncclCommInitRank");
+    R.CommInitAll = (decltype(R.CommInitAll))sym("ncclCommInitAll");
+    R.CommDestroy = (decltype(R.CommDestroy))sym("ncclCommDestroy");
+    R.Send = (decltype(R.Send))sym("ncclSend");
+    R.Recv = (decltype(R.Recv))sym("ncclRecv");
+    R.GroupStart = (decltype(R.GroupStart))sym("ncclGroupStart");
+    R.GroupEnd = (decltype(R.GroupEnd))sym("ncclGroupEnd");
+    R.GetErrorString = (decltype(R.GetErrorString))sym("ncclGetErrorString");
+    if (!ok) { dlclose(R.lib); R.lib = nullptr; }
+  });
+  if (!R.lib) { if (why) *why = R.err; return nullptr; }
+  return &R;
+}
+
+int rccl_fail(mrt_ctx *ctx, const Rccl *R, ncclResult_t r, const char *what)
+{
+  char buf[256];
+  std::snprintf(buf, sizeof buf, "RCCL error: %d (%s) in %s", (int)r, R ? R->GetErrorString(r) : "?", what);
+  return fail(ctx, MRT_ERR_HIP, buf);
+}
+} // namespace
+
+struct mrt_comm {
+  ncclComm_t comm = nullptr;
+  mrt_ctx *ctx = nullptr;
+  int rank = 0, nranks = 1;
+};
+
+#define RCCL_TRY(ctx, R, expr)                                        \
+  do {                                                                \
+    ncclResult_t r_ = (expr);                                         \
+    if (r_ != ncclSuccess) return rccl_fail((ctx), (R), r_, #expr);   \
+  } while (0)
+
+// dword offset of every rank's packed buffer in rank 0's staging area, and its length; `skip` sends nothing
+static uint64_t staging_layout(int W, int H, int nranks, int strip_rows, int skip, uint64_t *off, uint64_t *len)
+{
+  uint64_t o = 0;
+  mrt_partition p{0, nranks, strip_rows, 0};
+  for (int r = 0; r < nranks; ++r) {
+    p.rank = r;
+    off[r] = o;
+    len[r] = r == skip ? 0 : (uint64_t)local_rows_of(H, p) * (uint64_t)W * 5;
+    o += len[r];
+  }
+  return o;
+}
+
+extern "C" {
+
+int mrt_comm_unique_id(uint8_t id[MRT_COMM_ID_BYTES])
+{
+  if (!id) return MRT_ERR_INVALID;
+  std::string why;
+  const Rccl *R = rccl(&why);
+  if (!R) return fail(nullptr, MRT_ERR_HIP, why);
+  static_assert(sizeof(ncclUniqueId) == MRT_COMM_ID_BYTES, "ncclUniqueId is 128 bytes");
+  ncclUniqueId u;
+  RCCL_TRY(nullptr, R, R->GetUniqueId(&u));
+  std::memcpy(id, &u, sizeof u);
+  return MRT_OK;
+}
+
+int mrt_comm_create(mrt_ctx *ctx, const uint8_t id[MRT_COMM_ID_BYTES], int32_t rank, int32_t num_ranks, mrt_comm **out)
+{
+  if (!ctx || !id || !out) return MRT_ERR_INVALID;
+  *out = nullptr;
+  if (num_ranks < 1 || num_ranks > mrt::MAX_RANKS || rank < 0 || rank >= num_ranks)
+    return fail(ctx, MRT_ERR_INVALID, "mrt_comm_create: rank / num_ranks out of range (at most 64 ranks)");
+  std::string why;
+  const Rccl *R = rccl(&why);
+  if (!R) return fail(ctx, MRT_ERR_HIP, why);
+  mrt_comm *c = new (std::nothrow) mrt_comm();
+  if (!c) return fail(ctx, MRT_ERR_INVALID, "out of host memory");
+  c->ctx = ctx; c->rank = rank; c->nranks = num_ranks;
+  ncclUniqueId u;
+  std::memcpy(&u, id, sizeof u);
+  hipError_t e = hipSetDevice(ctx->device);
+  if (e != hipSuccess) { delete c; return hip_fail(ctx, e, "hipSetDevice"); }
+  ncclResult_t r = R->CommInitRank(&c->comm, num_ranks, u, rank);
+  if (r != ncclSuccess) { delete c; return rccl_fail(ctx, R, r, "ncclCommInitRank"); }
+  *out = c;
+  return MRT_OK;
+}
+
+int mrt_comm_create_local(mrt_ctx *const *ctxs, int32_t n, mrt_comm **out)
+{
+  if (!ctxs || !out || n < 1 || n > mrt::MAX_RANKS) return MRT_ERR_INVALID;
+  for (int i = 0; i < n; ++i) { out[i] = nullptr; if (!ctxs[i]) return MRT_ERR_INVALID; }
+  mrt_ctx *c0 = ctxs[0];
+  for (int i = 0; i < n; ++i)
+    for (int j = 0; j < i; ++j)
+      if (ctxs[i]->device == ctxs[j]->device) return fail(c0, MRT_ERR_INVALID, "mrt_comm_create_local: two contexts on one GPU");
+  std::string why;
+  const Rccl *R = rccl(&why);
+  if (!R) return fail(c0, MRT_ERR_HIP, why);
+  int devs[mrt::MAX_RANKS];
+  ncclComm_t comms[mrt::MAX_RANKS];
+  for (int i = 0; i < n; ++i) devs[i] = ctxs[i]->device;
+  RCCL_TRY(c0, R, R->CommInitAll(comms, n, devs));
+  for (int i = 0; i < n; ++i) {
+    mrt_comm *c = new (std::nothrow) mrt_comm();
+    if (!c) {
+      for (int j = 0; j < n; ++j) { (void)R->CommDestroy(comms[j]); delete out[j]; out[j] = nullptr; }
+      return fail(c0, MRT_ERR_INVALID, "out of host memory");
+    }
+    c->comm = comms[i]; c->ctx = ctxs[i]; c->rank = i; c->nranks = n;
+    out[i] = c;
+  }
+  return MRT_OK;
+}
+
+int mrt_comm_destroy(mrt_comm *comm)
+{
+  if (!comm) return MRT_OK;
+  const Rccl *R = rccl(nullptr);
+  int rc = MRT_OK;
+  if (R && comm->comm) {
+    if (comm->ctx) (void)hipSetDevice(comm->ctx->device);
+    ncclResult_t r = R->CommDestroy(comm->comm);
+    if (r != ncclSuccess) rc = rccl_fail(comm->ctx, R, r, "ncclCommDestroy");
+  }
+  delete comm;
+  return rc;
+}
+
+// scatter = false: the caller has a group open (the receives are only enqueued when it closes) and scatters itself
+static int gather_strips(mrt_ctx *ctx, mrt_comm *comm, const void *packed_dev, void *staging_dev, void *frame_rgb_dev,
+                         void *frame_id_dev, void *frame_t_dev, int32_t width, int32_t height, int32_t strip_rows,
+                         int32_t root_in_place, void *stream, bool scatter)
+{
+  if (!ctx || !comm) return MRT_ERR_INVALID;
+  if (comm->ctx != ctx) return fail(ctx, MRT_ERR_INVALID, "mrt_gather_strips: the communicator belongs to another context");
+  if (width <= 0 || height <= 0) return fail(ctx, MRT_ERR_INVALID, "non-positive frame size");
+  const int N = comm->nranks, me = comm->rank;
+  mrt_partition p{me, N, strip_rows, 0};
+  if (!partition_ok(p)) return fail(ctx, MRT_ERR_INVALID, "bad strip partition");
+  const Rccl *R = rccl(nullptr);
+  if (!R) return fail(ctx, MRT_ERR_HIP, "RCCL is not open");
+  const int skip = root_in_place ? 0 : -1;
+  uint64_t off[mrt::MAX_RANKS], len[mrt::MAX_RANKS];
+  staging_layout(width, height, N, strip_rows, skip, off, len);
+  hipStream_t st = (hipStream_t)stream;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  if (me != 0) {
+    if (len[me] == 0) return MRT_OK; // more ranks than strips: nothing to send (rank 0 posts no receive either)
+    if (!packed_dev) return fail(ctx, MRT_ERR_INVALID, "mrt_gather_strips: packed buffer is required on ranks other than 0");
+    RCCL_TRY(ctx, R, R->Send(packed_dev, (size_t)len[me], ncclFloat, 0, comm->comm, st));
+    return MRT_OK;
+  }
+  if (!frame_rgb_dev) return fail(ctx, MRT_ERR_INVALID, "mrt_gather_strips: rank 0 needs the frame buffers");
+  bool any = false;
+  for (int r = 0; r < N; ++r) any |= len[r] != 0;
+  if (!any) return MRT_OK; // one rank, rendered in place
+  if (!staging_dev) return fail(ctx, MRT_ERR_INVALID, "mrt_gather_strips: rank 0 needs the staging buffer");
+  if (!root_in_place && len[0] && !packed_dev) return fail(ctx, MRT_ERR_INVALID, "mrt_gather_strips: rank 0's packed buffer is required without root_in_place");
+  // one grouped batch: every peer's message lands at its offset (and rank 0's own, sent to itself, when asked)
+  RCCL_TRY(ctx, R, R->GroupStart());
+  ncclResult_t r1 = ncclSuccess;
+  if (!root_in_place && len[0]) r1 = R->Send(packed_dev, (size_t)len[0], ncclFloat, 0, comm->comm, st);
+  for (int r = 0; r < N && r1 == ncclSuccess; ++r)
+    if (len[r]) r1 = R->Recv((uint32_t *)staging_dev + off[r], (size_t)len[r], ncclFloat, r, comm->comm, st);
+  ncclResult_t r2 = R->GroupEnd();
+  if (r1 != ncclSuccess) return rccl_fail(ctx, R, r1, "ncclSend / ncclRecv");
+  if (r2 != ncclSuccess) return rccl_fail(ctx, R, r2, "ncclGroupEnd");
+  if (!scatter) return MRT_OK;
+  return mrt_scatter_strips(ctx, staging_dev, frame_rgb_dev, frame_id_dev, frame_t_dev, width, height, N, strip_rows, skip, stream);
+}
+
+int mrt_gather_strips(mrt_ctx *ctx, mrt_comm *comm, const void *packed_dev, void *staging_dev, void *frame_rgb_dev,
+                      void *frame_id_dev, void *frame_t_dev, int32_t width, int32_t height, int32_t strip_rows,
+                      int32_t root_in_place, void *stream)
+{
+  return gather_strips(ctx, comm, packed_dev, staging_dev, frame_rgb_dev, frame_id_dev, frame_t_dev, width, height,
+                       strip_rows, root_in_place, stream, true);
+}
+
+int mrt_render_multi(mrt_ctx *const *ctxs, mrt_comm *const *comms, int32_t n, const mrt_camera *cam,
+                     const mrt_render_params *params, float *rgb, int32_t *id, float *t, mrt_stats *stats)
+{
+  if (!ctxs || n < 1 || n > mrt::MAX_RANKS || !ctxs[0]) return MRT_ERR_INVALID;
+  mrt_ctx *c0 = ctxs[0];
+  if (!cam || !params) return MRT_ERR_INVALID;
+  if (!rgb) return fail(c0, MRT_ERR_INVALID, "rgb buffer is required");
+  for (int r = 0; r < n; ++r) {
+    if (!ctxs[r]) return fail(c0, MRT_ERR_INVALID, "mrt_render_multi: null context");
+    if (n > 1 && (!comms || !comms[r] || comms[r]->ctx != ctxs[r] || comms[r]->rank != r || comms[r]->nranks != n))
+      return fail(c0, MRT_ERR_INVALID, "mrt_render_multi: comms must be what mrt_comm_create_local returned for ctxs");
+  }
+  const int W = params->width, H = params->height, strip_rows = params->part.strip_rows;
+  uint64_t off[mrt::MAX_RANKS], len[mrt::MAX_RANKS];
+  mrt::RenderArgs A[mrt::MAX_RANKS];
+  // every rank's arguments first: nothing is enqueued before all of them are known to be valid
+  for (int r = 0; r < n; ++r) {
+    mrt_render_params p = *params;
+    p.part = mrt_partition{r, n, strip_rows, (n > 1 && r == 0) ? 1 : 0};
+    int rc = fill_args(ctxs[r], cam, &p, A[r]);
+    if (rc != MRT_OK) { if (r) fail(c0, rc, ctxs[r]->err); return rc; }
+  }
+  const uint64_t staging_dwords = staging_layout(W, H, n, strip_rows, 0, off, len);
+  const size_t npix = (size_t)W * H;
+  for (int r = 0; r < n; ++r) {
+    mrt_ctx *ctx = ctxs[r];
+    const size_t lpix = (size_t)A[r].local_rows * W;
+    // rank 0: the frame planes, then the staging area; other ranks: their packed rgb | id | t planes
+    const size_t need = (r == 0 ? (npix * 5 + (size_t)staging_dwords) : lpix * 5) * 4 + 256;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (ctx->out_bytes < need) {
+      HIP_TRY(ctx, drain(ctx));
+      if (ctx->out_mem) { HIP_TRY(ctx, hipFree(ctx->out_mem)); ctx->out_mem = nullptr; ctx->out_bytes = 0; }
+      HIP_TRY(ctx, hipMalloc(&ctx->out_mem, need));
+      ctx->out_bytes = need;
+    }
+    const size_t planes = r == 0 ? npix : lpix;
+    A[r].rgb = (float *)ctx->out_mem;
+    A[r].id = (int32_t *)((char *)ctx->out_mem + planes * 12);
+    A[r].t = (float *)((char *)ctx->out_mem + planes * 16);
+    A[r].stats = stats ? ctx->stats_dev : nullptr;
+    A[r].stats_slots = STATS_SLOTS;
+    HIP_TRY(ctx, order_after_last(ctx, ctx->stream));
+    if (A[r].stats) HIP_TRY(ctx, hipMemsetAsync(A[r].stats, 0, STATS_SLOTS * 8 * sizeof(unsigned long long), ctx->stream));
+    HIP_TRY(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+    HIP_TRY(ctx, launch_by_mode(ctx, A[r], ctx->stream));
+    HIP_TRY(ctx, hipEventRecord(ctx->ev1, ctx->stream));
+  }
+  if (n > 1) {
+    // The exchange of all ranks from this one thread: ONE group -- RCCL connects a pair of ranks when both sides have
+    // posted, and both sides are this thread.  Sends and receives are enqueued when the group closes, so rank 0's
+    // scatter is enqueued after that.
+    const Rccl *R = rccl(nullptr);
+    if (!R) return fail(c0, MRT_ERR_HIP, "RCCL is not open");
+    RCCL_TRY(c0, R, R->GroupStart());
+    int rc1 = MRT_OK;
+    for (int r = 0; r < n && rc1 == MRT_OK; ++r) {
+      mrt_ctx *ctx = ctxs[r];
+      void *staging = r == 0 ? (char *)ctx->out_mem + npix * 20 : nullptr;
+      rc1 = gather_strips(ctx, comms[r], r == 0 ? nullptr : ctx->out_mem, staging, r == 0 ? A[0].rgb : nullptr,
+                          r == 0 ? A[0].id : nullptr, r == 0 ? A[0].t : nullptr, W, H, strip_rows, 1, ctx->stream, false);
+      if (rc1 != MRT_OK && r) fail(c0, rc1, ctx->err);
+    }
+    ncclResult_t r2 = R->GroupEnd();
+    if (rc1 != MRT_OK) return rc1;
+    if (r2 != ncclSuccess) return rccl_fail(c0, R, r2, "ncclGroupEnd");
+    if (staging_dwords) {
+      rc1 = mrt_scatter_strips(c0, (char *)c0->out_mem + npix * 20, A[0].rgb, A[0].id, A[0].t, W, H, n, strip_rows, 0, c0->stream);
+      if (rc1 != MRT_OK) return rc1;
+    }
+  }
+  HIP_TRY(c0, hipSetDevice(c0->device));
+  HIP_TRY(c0, hipMemcpyAsync(rgb, A[0].rgb, npix * 12, hipMemcpyDeviceToHost, c0->stream));
+  if (id) HIP_TRY(c0, hipMemcpyAsync(id, A[0].id, npix * 4, hipMemcpyDeviceToHost, c0->stream));
+  if (t) HIP_TRY(c0, hipMemcpyAsync(t, A[0].t, npix * 4, hipMemcpyDeviceToHost, c0->stream));
+  unsigned long long h[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  float kernel_ms = 0.0f;
+  std::vector<unsigned long long> slots;
+  if (stats) {
+    try { slots.resize((size_t)STATS_SLOTS * 8); } catch (...) { return fail(c0, MRT_ERR_INVALID, "out of host memory"); }
+  }
+  for (int r = n - 1; r >= 0; --r) { // rank 0 last: its stream also carries the frame copy
+    mrt_ctx *ctx = ctxs[r];
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (stats) HIP_TRY(ctx, hipMemcpyAsync(slots.data(), ctx->stats_dev, slots.size() * sizeof(unsigned long long),
+                                           hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (stats) {
+      for (int s = 0; s < STATS_SLOTS; ++s)
+        for (int k = 0; k < 8; ++k) h[k] += slots[(size_t)s * 8 + k];
+      float ms = 0.0f;
+      HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+      kernel_ms = ms > kernel_ms ? ms : kernel_ms;
+    }
+  }
+  if (stats) {
+    stats->primary_rays = h[0]; stats->shadow_rays = h[1]; stats->hit_pixels = h[2]; stats->occluded = h[3];
+    stats->exact_tests = h[4]; stats->clusters_opened = h[5];
+    stats->kernel_ms = kernel_ms;
+  }
+  return MRT_OK;
 }
 
 } // extern "C"

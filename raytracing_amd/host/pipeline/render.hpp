@@ -130,4 +130,63 @@ private:
   mrt_ctx *ctx_ = nullptr;
 };
 
+// Several GPUs of this node, one process: the scene replicated on every GPU, the frame dealt to them in strips of
+// rows (strip s -> GPU s % N), the strips gathered on GPU 0 over RCCL and handed back as one frame
+// (mrt_render_multi).  The reference is single GPU (src/main.cu never selects a device); the frame is bit-identical
+// to Renderer's.  Fail-fast like Renderer.
+class MultiGpuRenderer {
+public:
+  explicit MultiGpuRenderer(int num_gpus, int strip_rows = 8) : strip_rows_(strip_rows)
+  {
+    ctxs_.assign(static_cast<std::size_t>(num_gpus > 0 ? num_gpus : 1), nullptr);
+    for (std::size_t i = 0; i < ctxs_.size(); ++i) checkRtErrors(mrt_ctx_create(static_cast<int>(i), &ctxs_[i]));
+    if (ctxs_.size() > 1) {
+      comms_.assign(ctxs_.size(), nullptr);
+      checkRtErrors(mrt_comm_create_local(ctxs_.data(), static_cast<std::int32_t>(ctxs_.size()), comms_.data()));
+    }
+  }
+  ~MultiGpuRenderer()
+  {
+    for (mrt_comm *c : comms_) mrt_comm_destroy(c);
+    for (mrt_ctx *c : ctxs_) mrt_ctx_destroy(c);
+  }
+  MultiGpuRenderer(const MultiGpuRenderer &) = delete;
+  MultiGpuRenderer &operator=(const MultiGpuRenderer &) = delete;
+
+  int num_gpus() const { return static_cast<int>(ctxs_.size()); }
+
+  void upload(const FlatScene &f)
+  {
+    mrt_scene_desc d = f.desc();
+    for (mrt_ctx *c : ctxs_) checkRtErrors(mrt_scene_upload(c, &d));
+  }
+  void upload(VectorView<SceneObject> objects, VectorView<Light> lights) { upload(flatten(objects, lights)); }
+
+  // whole frame, blocking; stats are sums over the GPUs, kernel_ms the slowest GPU's render kernel
+  mrt_stats render(const Viewport &viewport, ImageBuffer &img, int spp = 1, int max_depth = 0)
+  {
+    mrt_camera cam = viewport.to_abi();
+    mrt_render_params p{};
+    p.width = static_cast<std::int32_t>(img.width());
+    p.height = static_cast<std::int32_t>(img.height());
+    p.spp = spp;
+    p.max_depth = max_depth;
+    p.part = make_strip_partition(0, num_gpus(), strip_rows_);
+    mrt_stats st{};
+    checkRtErrors(mrt_render_multi(ctxs_.data(), comms_.empty() ? nullptr : comms_.data(), num_gpus(), &cam, &p,
+                                   &img.buffer()[0].x, img.ids(), img.ts(), &st));
+    return st;
+  }
+
+  void seed_random_streams(int seed)
+  {
+    for (mrt_ctx *c : ctxs_) checkRtErrors(mrt_ctx_set_option(c, MRT_OPT_RNG_SEED, seed));
+  }
+
+private:
+  std::vector<mrt_ctx *> ctxs_;
+  std::vector<mrt_comm *> comms_;
+  int strip_rows_;
+};
+
 } // namespace rt

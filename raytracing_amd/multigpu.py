@@ -8,7 +8,10 @@ copies the peers' strips from the staging area to their places in the three fram
 pass over the (N-1)/N of the frame that came from elsewhere; its own rows are never copied).  There is no other
 exchange step and no reference counterpart: the reference is single-GPU.
 
-torch is used for device memory, streams and the point-to-point transfers only.
+The exchange step has two carriers: mrt_gather_strips -- RCCL behind the C-ABI, on a communicator made from an id
+the ranks pass around (FrameRenderer.init_comm) -- and torch.distributed's point-to-point calls (RCCL too, under
+backend "nccl"; gloo for the CPU tests and rehearsals).  Same messages, same staging layout, same scatter kernel.
+torch is otherwise used for device memory and streams only.
 """
 import numpy as np
 
@@ -115,6 +118,17 @@ class FrameRenderer:
             self.rgb, self.ids, self.tt = self.packed[:n * 3], self.packed[n * 3:n * 4].view(torch.int32), self.packed[n * 4:]
             self.layout = 0
         self._call = None
+        self.comm = None
+
+    def init_comm(self, unique_id):
+        """Collective over the ranks: from now on the exchange step goes through mrt_gather_strips (RCCL behind the
+        C-ABI).  unique_id: the 128 bytes of capi.comm_unique_id() made on rank 0."""
+        self.comm = capi.Comm(self.ctx, unique_id, self.rank, self.num_ranks)
+
+    def drop_comm(self):
+        if self.comm is not None:
+            self.comm.close()
+            self.comm = None
 
     def render_local(self, want_stats=False):
         """Enqueue this rank's strips on torch's current stream (asynchronous)."""
@@ -135,6 +149,16 @@ class FrameRenderer:
     def collect(self):
         """The exchange step + rank 0's scatter (asynchronous on the current stream)."""
         if self.num_ranks == 1:
+            return
+        if self.comm is not None:
+            stream = self.torch.cuda.current_stream(self.dev).cuda_stream
+            if self.rank == 0:
+                self.ctx.gather_strips(self.comm, None, self.staging.data_ptr(), self.rgb.data_ptr(), self.ids.data_ptr(),
+                                       self.tt.data_ptr(), self.W, self.H, self.strip_rows, root_in_place=True,
+                                       stream=stream)
+            else:
+                self.ctx.gather_strips(self.comm, self.packed.data_ptr(), None, None, None, None, self.W, self.H,
+                                       self.strip_rows, root_in_place=True, stream=stream)
             return
         exchange_packed(self.packed, self.staging, self.offsets, self.rank, self.num_ranks, dst=0)
         if self.rank == 0:
@@ -164,4 +188,5 @@ class FrameRenderer:
                 "t": self.tt.view(self.H, self.W).cpu().numpy()}
 
     def close(self):
+        self.drop_comm()
         self.ctx.close()

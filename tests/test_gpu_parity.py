@@ -930,6 +930,13 @@ def test_cpp_host_layer_unit_tests_and_cli(gpu_ctx, tmp_path):
     # the CLI flips the image (row 0 of the file = top of the picture = the sky's upper part: bluer than white)
     px = np.frombuffer(data[len(head):], dtype=np.uint8).reshape(48, 96, 4)
     assert px[0, 0, 2] >= px[0, 0, 0]
+    assert "on 1 GPU(s)" in out.stdout
+    # more GPUs than the box has: the host layer's fail-fast convention (print and exit, src/check_error.cu:7-15)
+    import torch
+    more = torch.cuda.device_count() + 1
+    out = subprocess.run([os.path.join(lib, "raytracing"), str(hdr), "96", "48", "1", "0", str(more)], capture_output=True,
+                         text=True, timeout=100)
+    assert out.returncode != 0 and "MRT error" in out.stderr
 
 
 def test_device_render_on_a_side_stream_with_counters(gpu_ctx):
