@@ -141,10 +141,13 @@ const char *mrt_status_string(int status);
  * most 64 primitives, else 2).  All kernels produce identical buffers.  MRT_OPT_RNG_SEED (default 1984, the
  * constant of cuda_utils/curand_state.cuh:22; 0..2^31-1) seeds the per-pixel random streams of diffuse bounces:
  * pixel i of the full frame owns subsequence i, like curand_init(seed, i, 0, ...).
+ * MRT_OPT_CULL_TEAM (no reference counterpart; default 0, or environment MRT_CULL_TEAM): waves per tile in the tile-culling
+ * kernel -- 0 = by the scene, 1 = one wave per tile, 4 = four waves share a tile's leaf clusters, 5 = four waves share a
+ * tile's lights (scenes with many lights).  Identical buffers in every mode.
  * MRT_OPT_FAIL_NEXT_UPLOAD (test hook; value 1) makes the next mrt_scene_upload of the context fail at its
  * device allocation, after the old scene has been given up: the context must then report MRT_ERR_NO_SCENE.
  */
-enum { MRT_OPT_CULL = 1, MRT_OPT_RNG_SEED = 2, MRT_OPT_FAIL_NEXT_UPLOAD = 3 };
+enum { MRT_OPT_CULL = 1, MRT_OPT_RNG_SEED = 2, MRT_OPT_FAIL_NEXT_UPLOAD = 3, MRT_OPT_CULL_TEAM = 4 };
 int mrt_ctx_set_option(mrt_ctx *ctx, int option, int value);
 
 /*

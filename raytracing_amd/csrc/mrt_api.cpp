@@ -41,6 +41,7 @@ struct mrt_ctx {
   size_t out_bytes = 0;
   unsigned long long *stats_dev = nullptr;
   int cull = 1; // MRT_OPT_CULL value
+  int team = 0; // MRT_OPT_CULL_TEAM value
 
   // u = col / W, v = row / H tables of the small-scene kernel, one entry per frame size seen, kept until the
   // context goes (a frame size costs (W + H) floats)
@@ -295,6 +296,11 @@ int mrt_ctx_set_option(mrt_ctx *ctx, int option, int value)
   if (option == MRT_OPT_CULL) {
     if (!cull_mode_ok(value)) return fail(ctx, MRT_ERR_INVALID, "MRT_OPT_CULL takes 0, 1, 2 or 5");
     ctx->cull = value;
+    return MRT_OK;
+  }
+  if (option == MRT_OPT_CULL_TEAM) {
+    if (value != 0 && value != 1 && value != 4 && value != 5) return fail(ctx, MRT_ERR_INVALID, "MRT_OPT_CULL_TEAM takes 0, 1, 4 or 5");
+    ctx->team = value;
     return MRT_OK;
   }
   if (option == MRT_OPT_FAIL_NEXT_UPLOAD) {
@@ -617,6 +623,7 @@ static int fill_args(mrt_ctx *ctx, const mrt_camera *cam, const mrt_render_param
   A.spp = p->spp;
   A.max_depth = p->max_depth;
   A.stats_slots = 1;
+  A.team_mode = ctx->team;
   return MRT_OK;
 }
 

@@ -32,6 +32,17 @@
 
 namespace mrt {
 
+#ifdef MRT_TIMELINE
+// Diagnostic build only (make variant DEFS=-DMRT_TIMELINE; tools/timeline_cull.py): per wave the 100 MHz real-time
+// clock at entry and exit, the shader clock it lived, and how much it had to do.
+enum { TLC_WORDS = 4, TLC_MAX_WAVES = 1 << 18 };
+__device__ unsigned long long g_timeline_cull[TLC_WORDS * TLC_MAX_WAVES];
+extern "C" int mrt_diag_timeline_cull(unsigned long long *host_out, size_t words)
+{
+  return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_timeline_cull), words * sizeof(unsigned long long), 0, hipMemcpyDeviceToHost);
+}
+#endif
+
 template <int P> struct CVec;
 template <> struct CVec<1> { using f = float; using i = int; };
 template <> struct CVec<2> { typedef float f __attribute__((ext_vector_type(2))); typedef int i __attribute__((ext_vector_type(2))); };
@@ -40,8 +51,27 @@ template <> struct CVec<4> { typedef float f __attribute__((ext_vector_type(4)))
 // HIER: walk the cluster hierarchy (false: at most one cluster per primitive type).  P: horizontally adjacent
 // pixels per lane, i.e. a wave renders 8P x 8 pixels and pays for the walk once per tile.  MULTI: more than one
 // sample per pixel (false: no accumulation across samples, fewer registers).
-template <bool HIER, int P, bool MULTI>
-__global__ __launch_bounds__(256) void render_cull_kernel(RenderArgs A)
+//
+// NW: waves per tile.  1: every wave has a tile of its own and never meets another wave.  NW > 1: the workgroup's NW
+// waves are a TEAM on one tile -- all of them hold the tile's 64 rays and walk the upper levels of the hierarchy, but
+// the leaf clusters that survive (bound tests of 64 primitives + exact tests: where the time goes) are dealt round
+// robin, member w taking every NW-th.  Closest hit is an order-independent minimum over (t, object) and occlusion an
+// order-independent "any", so the members' partial results merge exactly: through LDS, once after the primary walks
+// and once per light.  Member 0 shades and stores.  This is for frames whose time is one tile's time: a tile of the
+// 64-light config takes 1.3 ms on one wave while the whole frame is 0.6 ms of work per wave slot (tools/timeline_cull.py).
+//
+// LSPLIT (teams only): the team deals LIGHTS instead of shadow leaves -- member w takes the lights w, w + NW, ... and
+// walks the scene for each of them on its own.  With many lights over a small scene a light's walk is short (two
+// exact tests per light and tile in the 64-light config) and what a tile costs is the per-light set-up, 64 times:
+// dealing leaves would repeat that set-up in every member.  The reference adds the lights' contributions to a pixel
+// in light order (core/light.cuh:171-173; fp32 addition does not associate), so a member does not add up its own
+// lights: it leaves each light's contribution in LDS, and member 0 folds them in order, 32 lights at a time.
+#ifndef MRT_CULL_TEAM_WAVES
+#define MRT_CULL_TEAM_WAVES 7
+#endif
+template <bool HIER, int P, bool MULTI, int NW, bool LSPLIT = false>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NW > 1 && !MULTI ? MRT_CULL_TEAM_WAVES : 1, 8)))
+void render_cull_kernel(RenderArgs A)
 {
   const DevScene &sc = A.sc;
   const DevCamera &cam = A.cam;
@@ -50,12 +80,32 @@ __global__ __launch_bounds__(256) void render_cull_kernel(RenderArgs A)
   const int tx = lane & 7, ty = lane >> 3;
   const int ns = sc.ns, nt = sc.nt;
   constexpr int TW = 8 * P;
+  static_assert(NW == 1 || P == 1, "teams render one pixel per lane");
+  constexpr int NWS = NW > 1 ? NW : 1;
+  __shared__ float tm_t[NW > 1 ? NWS * 64 : 1];            // members' closest hits, [member][lane]
+  __shared__ int tm_obj[NW > 1 ? NWS * 64 : 1], tm_prim[NW > 1 ? NWS * 64 : 1];
+  __shared__ unsigned long long tm_open[NW > 1 ? 2 * NWS : 1]; // members' still-unoccluded masks, [light parity][member]
+  static_assert(!LSPLIT || NW > 1, "lights are dealt among the members of a team");
+#ifndef MRT_CULL_LCH
+#define MRT_CULL_LCH 16
+#endif
+  constexpr int LCH = MRT_CULL_LCH;                            // lights per fold
+  __shared__ float tm_c[LSPLIT ? 3 * LCH * 64 : 1];            // a light's contribution, [channel][light % LCH][lane]
+  __shared__ unsigned long long tm_lit[LSPLIT ? LCH : 1];      // lanes the light contributes to
+  const int member = NW > 1 ? wave : 0;
 
   // 2-D grid: blockIdx.y = tile row, blockIdx.x*4 + wave = tile column (both wave-uniform, so the strip
-  // arithmetic below runs on the scalar unit)
-  const int tile_x = blockIdx.x * (blockDim.x >> 6) + wave;
+  // arithmetic below runs on the scalar unit); a team's tile column is its workgroup's index
+  const int tile_x = NW > 1 ? int(blockIdx.x) : int(blockIdx.x * (blockDim.x >> 6) + wave);
   const int tile_y = blockIdx.y;
-  if (tile_x * TW >= A.W) return; // waves are independent: no barrier anywhere below
+  if (tile_x * TW >= A.W) return; // NW == 1: waves are independent; NW > 1: the whole team leaves
+  int leaf_k = 0; // leaf clusters met so far in the current walk (the same sequence in every member)
+#define MRT_TEAM_TAKES_LEAF() (NW == 1 || (leaf_k++ % NWS) == member)
+#define MRT_TEAM_TAKES_SHADOW_LEAF() (NW == 1 || LSPLIT || (leaf_k++ % NWS) == member)
+#ifdef MRT_TIMELINE
+  const unsigned tl_idx = tile_y * ((A.W + TW - 1) / TW) + tile_x;
+  const unsigned long long tl_rt0 = __builtin_amdgcn_s_memrealtime(), tl_c0 = __builtin_amdgcn_s_memtime();
+#endif
   const int col0 = tile_x * TW + tx * P;
   const int lrow = tile_y * 8 + ty;
   // strips are multiples of 8 rows, so a tile never straddles two strips
@@ -73,12 +123,20 @@ __global__ __launch_bounds__(256) void render_cull_kernel(RenderArgs A)
   //      ray of the padded tile is the centre ray plus an offset of norm <= cone_ext (launcher): the angle
   //      to the centre ray is at most asin(cone_ext / |centre ray|). ----
   float cax, cay, caz, cosT, sinT;
+  float dcx, dcy, dcz, cam_round;          // the tile's centre ray, not normalised; rounding of a ray's direction
+  float ehx, ehy, ehz, evx, evy, evz;      // half the padded tile's extent along the camera's horizontal / vertical
+  constexpr int TRI_REFINE_MIN = 4;        // candidates in a leaf from which the per-triangle refinement runs
   {
     const float rw = fast_rcp(float(A.W)), rh = fast_rcp(float(A.H)); // bound arithmetic: approximate is fine
     const float um = (float(tile_x * TW) + 0.5f * float(TW - 1)) * rw, vm = (float(grow0) + 3.5f) * rh;
     cax = ((cam.ux + um * cam.hx) + vm * cam.vx) - cam.ox;
     cay = ((cam.uy + um * cam.hy) + vm * cam.vy) - cam.oy;
     caz = ((cam.uz + um * cam.hz) + vm * cam.vz) - cam.oz;
+    dcx = cax; dcy = cay; dcz = caz;
+    cam_round = 2.0f * camera_rounding(cam); // a ray's and the centre ray's
+    const float du = (0.5f * float(TW) + 0.51f) * rw * 1.001f, dv = 4.51f * rh * 1.001f; // pixels -1 .. 8P, -1 .. 8
+    ehx = du * cam.hx; ehy = du * cam.hy; ehz = du * cam.hz;
+    evx = dv * cam.vx; evy = dv * cam.vy; evz = dv * cam.vz;
     const float inv = fast_rsq(dot3(cax, cay, caz, cax, cay, caz));
     cax *= inv; cay *= inv; caz *= inv;
     sinT = A.cone_ext * inv * (1.0f + 1e-4f) + 1e-6f;
@@ -128,8 +186,40 @@ __global__ __launch_bounds__(256) void render_cull_kernel(RenderArgs A)
       best_t[p] = MRT_INF; best_obj[p] = 0x7fffffff; best_prim[p] = -1;
     }
 
+    // ---- depth bound of the tile: once every pixel of the tile has a hit, nothing farther than the farthest of
+    //      them can win anywhere in the tile (the closest-hit rule takes t < best, or t == best with a lower object
+    //      number).  A hit at parameter t lies t |d| from the camera, so a primitive whose bound starts farther than
+    //      tile_tmax * max |d| away is skipped, as are its cluster and super-cluster.  Wave-uniform, refreshed
+    //      after every leaf that moved a best_t; +inf while a pixel (inside the frame) has no hit.  Margin 1e-4
+    //      (relative) against a rounding of 1e-6 in the exact tests' t and hit points. ----
+    float dlen_max = 0.0f;
+#pragma unroll
+    for (int p = 0; p < P; ++p) dlen_max = fmaxf(dlen_max, aa[p]);
+    dlen_max = fast_sqrt(wave_max(dlen_max)) * (1.0f + 1e-5f);
+    float reach_max = MRT_INF; // tile_tmax * max |d| * (1 + 1e-4)
+    auto refresh_reach = [&]() {
+      float m = 0.0f;
+#pragma unroll
+      for (int p = 0; p < P; ++p) m = fmaxf(m, valid[p] ? best_t[p] : 0.0f);
+      reach_max = wave_max(m) * dlen_max * (1.0f + 1e-4f) + 1e-6f; // +inf stays +inf; NaN never culls (compares false)
+    };
+    auto sphere_ball_in_reach = [&](float x, float y, float z, float R) {
+      if (!cone_vs_sphere_ball(x, y, z, R)) return false;
+      const float wx = x - cam.ox, wy = y - cam.oy, wz = z - cam.oz;
+      const float L = fast_sqrt(dot3(wx, wy, wz, wx, wy, wz));
+      return !(L * (1.0f - 1e-5f) - cluster_cull_radius(R, L * CULL_REL + R) > reach_max);
+    };
+    // (Triangles get no such test on their bounding balls: far from the world origin the exact test's
+    // t = (k - n.o) / (n.d) cancels catastrophically in k - n.o and is off by 1e-7 (|k| + |n||o|) / |n.d|, without
+    // bound for grazing rays, so a t computed NEARER than the ball can win.  Found by tools/stress_parity.py with the
+    // scene moved 1e5 units.  Their depth test is the plane test of the leaf refinement below, which starts from
+    // the very same fp32 k - n.o.)
+    auto tri_ball_in_reach = [&](float x, float y, float z, float R) { return cone_vs_tri_ball(x, y, z, R); };
+
     // ---- closest hit over spheres: src/main.cu:60-77, core/sphere.cuh:32-73, interval [0.01, inf] ----
-    walk_hierarchy<HIER>(sc.sph_sclu, sc.nscs, sc.sph_clu, sc.ncs, lane, cone_vs_sphere_ball, [&](int base) {
+    leaf_k = 0;
+    walk_hierarchy<HIER>(sc.sph_sclu, sc.nscs, sc.sph_clu, sc.ncs, lane, sphere_ball_in_reach, [&](int base) {
+      if (!MRT_TEAM_TAKES_LEAF()) return true;
       const int i = base + lane;
       float cx = 0.0f, cy = 0.0f, cz = 0.0f, r = 0.0f;
       bool pass = false;
@@ -137,10 +227,13 @@ __global__ __launch_bounds__(256) void render_cull_kernel(RenderArgs A)
         cx = sc.sph_cx[i]; cy = sc.sph_cy[i]; cz = sc.sph_cz[i]; r = sc.sph_r[i];
         const float wx = cx - cam.ox, wy = cy - cam.oy, wz = cz - cam.oz;
         const float L2 = dot3(wx, wy, wz, wx, wy, wz);
-        pass = ball_may_touch_cone(wx, wy, wz, sphere_cull_radius(r * r, L2), cax, cay, caz, cosT, sinT);
+        const float reff = sphere_cull_radius(r * r, L2);
+        pass = ball_may_touch_cone(wx, wy, wz, reff, cax, cay, caz, cosT, sinT) &&
+               !(fast_sqrt(L2) * (1.0f - 1e-5f) - reff > reach_max);
       }
       unsigned long long mask = __ballot(pass);
       n_clusters++; n_exact += __popcll(mask);
+      bool moved = false;
       while (mask) {
         const int j = __builtin_ctzll(mask);
         mask &= mask - 1;
@@ -156,22 +249,81 @@ __global__ __launch_bounds__(256) void render_cull_kernel(RenderArgs A)
             float t;
             if (sphere_roots(aa[p], b, disc, 0.01f, MRT_INF, t)) {
               if (t < best_t[p] || (t == best_t[p] && t < MRT_INF && obj < best_obj[p])) {
-                best_t[p] = t; best_obj[p] = obj; best_prim[p] = base + j;
+                best_t[p] = t; best_obj[p] = obj; best_prim[p] = base + j; moved = true;
               }
             }
           }
         }
       }
+      if (NW == 1 && __any(moved)) refresh_reach(); // (a team member only knows its own hits: it keeps +inf)
       return true;
     });
 
     // ---- closest hit over triangles: core/triangle.cuh:77-103 ----
-    walk_hierarchy<HIER>(sc.tri_sclu, sc.nsct, sc.tri_clu, sc.nct, lane, cone_vs_tri_ball, [&](int base) {
+    walk_hierarchy<HIER>(sc.tri_sclu, sc.nsct, sc.tri_clu, sc.nct, lane, tri_ball_in_reach, [&](int base) {
+      if (!MRT_TEAM_TAKES_LEAF()) return true;
       const int i = base + lane;
       bool pass = false;
-      if (i < nt) pass = cone_vs_tri_ball(sc.tri_bx[i], sc.tri_by[i], sc.tri_bz[i], sc.tri_br[i]);
+      if (i < nt) pass = tri_ball_in_reach(sc.tri_bx[i], sc.tri_by[i], sc.tri_bz[i], sc.tri_br[i]);
+      if (HIER && __popcll(__ballot(pass)) >= TRI_REFINE_MIN && pass) {
+        // Many candidates in one leaf (the usual leaf has one to three): worth a closer look at each, lane-parallel,
+        // before the wave spends a division and up to three edge tests on every one of them for all its pixels.
+        //
+        // (1) The triangle's PLANE against the tile's cone: t = (k - n.o) / (n.d), and over the cone's unit
+        // directions n.u stays within c cos(theta) -+ s sin(theta), c = n.axis, s = |n - c axis|.  If that range
+        // keeps one sign, either every ray of the tile meets the plane behind the camera (the exact test wants
+        // t >= 0.01), or at t >= |k - n.o| / (max |n.u| max |d|): beyond the tile's depth bound it cannot win.
+        // (2) The EDGE planes in screen space (as the small-scene kernel does, mrt_small.hip): with the sign of n.d
+        // fixed, e_i(p) |n.d| = +-w_i.d, w_i = (m_i.o - c_i) n + (k - n.o) m_i, which is affine in the pixel
+        // coordinates: its maximum over the padded tile is its value at the tile's centre plus a constant.  Below
+        // the exact test's -1e-6 (and a margin of 1e-4 of every magnitude that enters either computation; the
+        // exact test rounds at 6e-8): no ray of the tile passes edge i.
+        // This is what deals with triangles that have no finite bound -- the reference's edge planes accept an
+        // unbounded wedge when a triangle's plane passes near the world origin: 223 of the 1M-triangle terrain,
+        // which every tile used to test -- and with the long slivers along a horizon.
+        const size_t snt = size_t(nt);
+        const float pnx = sc.tri[i], pny = sc.tri[snt + i], pnz = sc.tri[2 * snt + i], kp = sc.tri[3 * snt + i];
+        const float num = kp - dot3(cam.ox, cam.oy, cam.oz, pnx, pny, pnz);
+        const float c = dot3(pnx, pny, pnz, cax, cay, caz);
+        const float qx = pnx - c * cax, qy = pny - c * cay, qz = pnz - c * caz;
+        const float sp = fast_sqrt(dot3(qx, qy, qz, qx, qy, qz));
+        const float pn1 = norm1(pnx, pny, pnz);
+        const float slack = 2e-5f * pn1;
+        const float lo = c * cosT - sp * sinT - slack, hi = c * cosT + sp * sinT + slack;
+        if (cosT > 0.0f && (lo > 0.0f || hi < 0.0f)) { // (cosT = -1: the cone cannot cull)
+          // max |n.u| over the cone: cos(phi - theta) for a normal at angle phi >= theta from the axis -- but a normal
+          // INSIDE the cone (phi < theta: a wall seen head-on, or any normal once rounding has widened the cone far
+          // from the world origin) is some ray's direction, and the maximum is |n|
+          const bool inside = sp * cosT <= fabsf(c) * sinT * 1.01f + slack;
+          const float big = inside ? pn1 : fmaxf(fabsf(lo), fabsf(hi));
+          const bool behind = (lo > 0.0f) ? (num < 0.0f) : (num > 0.0f);
+          const float o1 = norm1(cam.ox, cam.oy, cam.oz);
+          if (behind && fabsf(num) > 1e-4f * (fabsf(kp) + o1 * pn1)) pass = false;
+          else if (fabsf(num) * (1.0f - 1e-4f) > reach_max * big) pass = false;
+          if (pass) {
+            const float sgn = lo > 0.0f ? 1.0f : -1.0f;
+            const float dl = dlen_max * 1.01f; // the padded tile's rays are a little longer than the pixels'
+#pragma unroll
+            for (int e = 0; e < 3; ++e) {
+              const float mx = sc.tri[(4 + 4 * e) * snt + i], my = sc.tri[(5 + 4 * e) * snt + i],
+                          mz = sc.tri[(6 + 4 * e) * snt + i], ce = sc.tri[(7 + 4 * e) * snt + i];
+              const float a = dot3(mx, my, mz, cam.ox, cam.oy, cam.oz) - ce;
+              const float wx = a * pnx + num * mx, wy = a * pny + num * my, wz = a * pnz + num * mz;
+              const float top = sgn * dot3(wx, wy, wz, dcx, dcy, dcz) + fabsf(dot3(wx, wy, wz, ehx, ehy, ehz)) +
+                                fabsf(dot3(wx, wy, wz, evx, evy, evz));
+              const float m1 = norm1(mx, my, mz);
+              // 1e-4 of the magnitudes behind w.d and behind the exact test's e_i |n.d|; the rounding of the rays
+              // themselves (coarse far from the world origin: camera_rounding) through |w|; the exact test's -1e-6
+              const float err = 1e-4f * ((m1 * o1 + fabsf(ce)) * pn1 + fabsf(num) * m1) * (2.0f * dl) +
+                                norm1(wx, wy, wz) * cam_round + 1e-6f * big * dl;
+              if (top + err < 0.0f) pass = false; // NaN compares false: never culls
+            }
+          }
+        }
+      }
       unsigned long long mask = __ballot(pass);
       n_clusters++; n_exact += __popcll(mask);
+      bool moved = false;
       while (mask) {
         const int j = __builtin_ctzll(mask);
         mask &= mask - 1;
@@ -194,13 +346,30 @@ __global__ __launch_bounds__(256) void render_cull_kernel(RenderArgs A)
           const bool hit = (rdn != 0.0f) & (e0 > -1e-6f) & (e1 > -1e-6f) & (e2 > -1e-6f) & (0.01f <= t) & (t <= MRT_INF);
           if (hit) {
             if (t < best_t[p] || (t == best_t[p] && t < MRT_INF && obj < best_obj[p])) {
-              best_t[p] = t; best_obj[p] = obj; best_prim[p] = ns + base + j;
+              best_t[p] = t; best_obj[p] = obj; best_prim[p] = ns + base + j; moved = true;
             }
           }
         }
       }
+      if (NW == 1 && __any(moved)) refresh_reach();
       return true;
     });
+
+    if constexpr (NW > 1) {
+      // the team's closest hit: the minimum of the members' (t, object) under the same rule as inside a member
+      tm_t[member * 64 + lane] = best_t[0]; tm_obj[member * 64 + lane] = best_obj[0]; tm_prim[member * 64 + lane] = best_prim[0];
+      __syncthreads();
+      best_t[0] = MRT_INF; best_obj[0] = 0x7fffffff; best_prim[0] = -1;
+#pragma unroll
+      for (int w = 0; w < NWS; ++w) {
+        const float t = tm_t[w * 64 + lane];
+        const int obj = tm_obj[w * 64 + lane], prim = tm_prim[w * 64 + lane];
+        if (prim >= 0 && (t < best_t[0] || (t == best_t[0] && t < MRT_INF && obj < best_obj[0]))) {
+          best_t[0] = t; best_obj[0] = obj; best_prim[0] = prim;
+        }
+      }
+      if (MULTI) __syncthreads(); // the next sample writes these slots again
+    }
 
     // ---- hit record of the winner (core/sphere.cuh:45-47, core/triangle.cuh:96-97) ----
     bool have_hit[P], any_hit_lane = false;
@@ -222,7 +391,7 @@ __global__ __launch_bounds__(256) void render_cull_kernel(RenderArgs A)
           const bool front = dot3(dx[p], dy[p], dz[p], pnx, pny, pnz) < 0;
           hnx[p] = front ? pnx : -pnx; hny[p] = front ? pny : -pny; hnz[p] = front ? pnz : -pnz;
         }
-        if (valid[p]) n_hit++;
+        if (valid[p] && member == 0) n_hit++;
       }
     }
 
@@ -336,8 +505,11 @@ __global__ __launch_bounds__(256) void render_cull_kernel(RenderArgs A)
         }
 
         // any-hit over spheres, interval [1e-3, t_light] (core/light.cuh:28-33)
-        if (__any(any_open))
+        const bool team_need = __any(any_open); // from the merged hit records: the same in every member of a team
+        leaf_k = 0;
+        if (team_need)
           walk_hierarchy<HIER>(sc.sph_sclu, sc.nscs, sc.sph_clu, sc.ncs, lane, bundle_vs_sphere_ball, [&](int base) {
+            if (!MRT_TEAM_TAKES_SHADOW_LEAF()) return true;
             const int i = base + lane;
             float cx = 0.0f, cy = 0.0f, cz = 0.0f, r = 0.0f;
             bool pass = false;
@@ -373,9 +545,11 @@ __global__ __launch_bounds__(256) void render_cull_kernel(RenderArgs A)
         any_open = false;
 #pragma unroll
         for (int p = 0; p < P; ++p) any_open |= open[p];
-        // any-hit over triangles
+        // any-hit over triangles (a member whose sphere walk ended early has met fewer leaves: count afresh)
+        leaf_k = 0;
         if (__any(any_open))
           walk_hierarchy<HIER>(sc.tri_sclu, sc.nsct, sc.tri_clu, sc.nct, lane, bundle_vs_tri_ball, [&](int base) {
+            if (!MRT_TEAM_TAKES_SHADOW_LEAF()) return true;
             const int i = base + lane;
             bool pass = false;
             if (i < nt) pass = bundle_may_touch(B, sc.tri_bx[i], sc.tri_by[i], sc.tri_bz[i], sc.tri_br[i]);
@@ -390,7 +564,8 @@ __global__ __launch_bounds__(256) void render_cull_kernel(RenderArgs A)
 #pragma unroll
               for (int p = 0; p < P; ++p) {
                 const float rdn = dot3(sdx[ix(p)], sdy[ix(p)], sdz[ix(p)], pnx, pny, pnz);
-                const float t = (kp - dot3(hpx[p], hpy[p], hpz[p], pnx, pny, pnz)) / rdn;
+                const float snum = kp - dot3(hpx[p], hpy[p], hpz[p], pnx, pny, pnz);
+                const float t = snum / rdn;
                 if (!__any(open[p] & (rdn != 0.0f) & (1e-3f <= t) & (t <= tl))) { still |= open[p]; continue; }
                 const float px = hpx[p] + t * sdx[ix(p)], py = hpy[p] + t * sdy[ix(p)], pz = hpz[p] + t * sdz[ix(p)];
                 const float e0 = dot3(q[4], q[5], q[6], px, py, pz) - q[7];
@@ -405,6 +580,20 @@ __global__ __launch_bounds__(256) void render_cull_kernel(RenderArgs A)
             return true;
           });
 
+        if constexpr (NW > 1 && !LSPLIT) {
+          if (team_need) {
+            // a shadow ray is free only if no member found an occluder: AND of the members' masks (slots alternate
+            // between lights, so one barrier per light is enough)
+            const unsigned long long mine = __ballot(open[0]);
+            if (lane == 0) tm_open[(li & 1) * NWS + member] = mine;
+            __syncthreads();
+            unsigned long long all = ~0ull;
+#pragma unroll
+            for (int w = 0; w < NWS; ++w) all &= tm_open[(li & 1) * NWS + w];
+            open[0] = (all >> lane) & 1ull;
+          }
+          if (member != 0) return; // member 0 shades
+        }
         const float lcr = sc.light_rgb[3 * li], lcg = sc.light_rgb[3 * li + 1], lcb = sc.light_rgb[3 * li + 2];
 #pragma unroll
         for (int p = 0; p < P; ++p) {
@@ -423,19 +612,46 @@ __global__ __launch_bounds__(256) void render_cull_kernel(RenderArgs A)
               if (dot3(rx, ry, rz, dx[p], dy[p], dz[p]) < -0.99f) { cr = lcr; cg = lcg; cb = lcb; }
               else { cr = 0.001f; cg = 0.001f; cb = 0.001f; }
             }
-            if (have_light[p]) { lr[p] += cr; lg[p] += cg; lb[p] += cb; }
-            else { lr[p] = cr; lg[p] = cg; lb[p] = cb; have_light[p] = true; }
+            if constexpr (LSPLIT) {
+              tm_c[(0 * LCH + (li & (LCH - 1))) * 64 + lane] = cr;
+              tm_c[(1 * LCH + (li & (LCH - 1))) * 64 + lane] = cg;
+              tm_c[(2 * LCH + (li & (LCH - 1))) * 64 + lane] = cb;
+            } else {
+              if (have_light[p]) { lr[p] += cr; lg[p] += cg; lb[p] += cb; }
+              else { lr[p] = cr; lg[p] = cg; lb[p] = cb; have_light[p] = true; }
+            }
           }
+        }
+        if constexpr (LSPLIT) {
+          const unsigned long long lit = __ballot(open[0]);
+          if (lane == 0) tm_lit[li & (LCH - 1)] = lit;
         }
       };
       for (int li = 0; li < sc.nl; ++li) {
-        const float lvx = sc.light_vec[3 * li], lvy = sc.light_vec[3 * li + 1], lvz = sc.light_vec[3 * li + 2];
-        if (sc.light_kind[li] == 0) shade_light(std::false_type{}, li, lvx, lvy, lvz);
-        else shade_light(std::true_type{}, li, lvx, lvy, lvz);
+        if (!LSPLIT || (li % NWS) == member) {
+          const float lvx = sc.light_vec[3 * li], lvy = sc.light_vec[3 * li + 1], lvz = sc.light_vec[3 * li + 2];
+          if (sc.light_kind[li] == 0) shade_light(std::false_type{}, li, lvx, lvy, lvz);
+          else shade_light(std::true_type{}, li, lvx, lvy, lvz);
+        }
+        if constexpr (LSPLIT) {
+          if ((li & (LCH - 1)) == LCH - 1 || li == sc.nl - 1) {
+            __syncthreads(); // the chunk's contributions are in LDS
+            if (member == 0)
+              for (int k = li & ~(LCH - 1); k <= li; ++k) // result += light_bounce(...), in light order: core/light.cuh:171-173
+                if ((tm_lit[k & (LCH - 1)] >> lane) & 1ull) {
+                  const float cr = tm_c[(0 * LCH + (k & (LCH - 1))) * 64 + lane], cg = tm_c[(1 * LCH + (k & (LCH - 1))) * 64 + lane],
+                              cb = tm_c[(2 * LCH + (k & (LCH - 1))) * 64 + lane];
+                  if (have_light[0]) { lr[0] += cr; lg[0] += cg; lb[0] += cb; }
+                  else { lr[0] = cr; lg[0] = cg; lb[0] = cb; have_light[0] = true; }
+                }
+            __syncthreads(); // the slots are free for the next chunk
+          }
+        }
       }
     }
 
     // ---- combine: src/main.cu:91-104 with MAX_RECURSION_DEPTH = 0 ----
+    if (NW > 1 && member != 0) continue;
 #pragma unroll
     for (int p = 0; p < P; ++p) {
       float cr, cg, cb;
@@ -465,7 +681,9 @@ __global__ __launch_bounds__(256) void render_cull_kernel(RenderArgs A)
     for (int p = 0; p < P; ++p) { accr[p] = accr[p] / fn; accg[p] = accg[p] / fn; accb[p] = accb[p] / fn; }
   }
   const size_t pix0 = size_t(A.frame_layout ? grow : lrow) * A.W + col0;
-  if (P > 1 && A.wide && valid_row && col0 + P <= A.W) {
+  if (NW > 1 && member != 0) {
+    // the other members only report the work they did
+  } else if (P > 1 && A.wide && valid_row && col0 + P <= A.W) {
     // the lane's 3P floats / P ints / P floats are contiguous and 4P-byte aligned (launcher checks W and pointers)
     using VF = typename CVec<P>::f;
     using VI = typename CVec<P>::i;
@@ -489,6 +707,13 @@ __global__ __launch_bounds__(256) void render_cull_kernel(RenderArgs A)
       }
   }
 
+#ifdef MRT_TIMELINE
+  if (tl_idx < TLC_MAX_WAVES && lane == 0 && member == 0) {
+    unsigned long long *tlp = g_timeline_cull + (size_t)TLC_WORDS * tl_idx;
+    tlp[0] = tl_rt0; tlp[1] = __builtin_amdgcn_s_memrealtime(); tlp[2] = __builtin_amdgcn_s_memtime() - tl_c0;
+    tlp[3] = (unsigned long long)n_exact | ((unsigned long long)n_clusters << 32);
+  }
+#endif
   if (A.stats) {
     // counters are spread over stats_slots copies: same-address atomics cost ~12 ns each, one after the other
     unsigned long long *st = A.stats + 8u * ((blockIdx.x + 7u * blockIdx.y) & (unsigned)(A.stats_slots - 1));
@@ -498,6 +723,9 @@ __global__ __launch_bounds__(256) void render_cull_kernel(RenderArgs A)
     unsigned int v4[4] = {nvalid * (unsigned)(MULTI ? A.spp : 1), n_shadow, n_hit, n_occl};
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
+      // a team's pixels and hits are counted by member 0; shadow rays by whoever traced them (member 0, or with
+      // the lights dealt out every member for its own lights)
+      if (NW > 1 && member != 0 && !(LSPLIT && (k == 1 || k == 3))) continue;
       unsigned int x = v4[k];
       for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, 64);
       if (lane == 0 && x) atomicAdd(&st[k], (unsigned long long)x);
@@ -507,6 +735,27 @@ __global__ __launch_bounds__(256) void render_cull_kernel(RenderArgs A)
       atomicAdd(&st[5], (unsigned long long)n_clusters);
     }
   }
+}
+
+// Waves per tile for a scene (render_cull_kernel's NW and LSPLIT).  A team pays for itself when single tiles are long
+// jobs: many lights (every hit tile walks the scene once per light) or a very large scene (tiles along a horizon
+// open hundreds of clusters).  Measured (tools/timeline_cull.py): 64 point lights over 512 primitives
+// 1.60 -> 1.17 ms dealing lights (2.9 ms dealing leaves), 1M triangles 5.4 -> 4.4 ms dealing leaves; 10k spheres under
+// one light are faster without teams (0.41 against 0.94 ms).
+// -> 1: one wave per tile; 4: teams dealing leaves; 5: teams dealing lights.  MRT_OPT_CULL_TEAM (or environment
+// MRT_CULL_TEAM, read once) = 1 | 4 | 5 pins it; 0 = by the scene: lights from 8 lights on, leaves from 100 000
+// primitives on.
+static int team_mode(const RenderArgs &A)
+{
+  static const int env = [] {
+    const char *e = getenv("MRT_CULL_TEAM");
+    const int x = e ? atoi(e) : 0;
+    return (x == 1 || x == 4 || x == 5) ? x : 0;
+  }();
+  const int forced = A.team_mode ? A.team_mode : env;
+  if (forced) return forced;
+  if (A.sc.nl >= 8) return 5;
+  return (long)A.sc.ns + A.sc.nt >= 100000 ? 4 : 1;
 }
 
 template <bool HIER, int P>
@@ -529,9 +778,23 @@ static hipError_t launch_cull(RenderArgs &A, hipStream_t stream)
   if (tiles_x == 0 || tiles_y == 0) return hipSuccess;
   // waves per workgroup: waves share nothing; 2 measured best on C3 and C5 (413 / 1561 us against 444 / 1625 with 4)
   static const int wpw = getenv("MRT_CULL_WPW") ? atoi(getenv("MRT_CULL_WPW")) : 2;
+  if constexpr (HIER && P == 1) {
+    const int team = team_mode(A);
+    if (team != 1) { // one workgroup of four waves per tile
+      const dim3 tgrid(tiles_x, tiles_y);
+      if (team == 5) {                  // the members deal the lights
+        if (A.spp > 1) hipLaunchKernelGGL((render_cull_kernel<true, 1, true, 4, true>), tgrid, dim3(256), 0, stream, A);
+        else hipLaunchKernelGGL((render_cull_kernel<true, 1, false, 4, true>), tgrid, dim3(256), 0, stream, A);
+      } else {                          // ... or the leaves of every walk
+        if (A.spp > 1) hipLaunchKernelGGL((render_cull_kernel<true, 1, true, 4, false>), tgrid, dim3(256), 0, stream, A);
+        else hipLaunchKernelGGL((render_cull_kernel<true, 1, false, 4, false>), tgrid, dim3(256), 0, stream, A);
+      }
+      return hipGetLastError();
+    }
+  }
   const dim3 grid((tiles_x + wpw - 1) / wpw, tiles_y);
-  if (A.spp > 1) hipLaunchKernelGGL((render_cull_kernel<HIER, P, true>), grid, dim3(64 * wpw), 0, stream, A);
-  else hipLaunchKernelGGL((render_cull_kernel<HIER, P, false>), grid, dim3(64 * wpw), 0, stream, A);
+  if (A.spp > 1) hipLaunchKernelGGL((render_cull_kernel<HIER, P, true, 1>), grid, dim3(64 * wpw), 0, stream, A);
+  else hipLaunchKernelGGL((render_cull_kernel<HIER, P, false, 1>), grid, dim3(64 * wpw), 0, stream, A);
   return hipGetLastError();
 }
 

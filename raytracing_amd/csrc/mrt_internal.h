@@ -88,6 +88,7 @@ struct RenderArgs {
   const float *utab, *vtab;
   int32_t wide;
   float cone_ext;                   // cull kernel: max |ray - tile centre ray| over a padded tile (launcher)
+  int32_t team_mode;                // cull kernel, MRT_OPT_CULL_TEAM: 0 automatic, 1 one wave per tile, 4 teams dealing leaves, 5 dealing lights
   // diffuse bounces (mrt_bounce.hip, mrt_rng.hip): xorshift words of pixel i at rng[k * rng_stride + i], k = 0..4,
   // and the Weyl counter every stream starts with; null when no stream is needed
   const uint32_t *rng;

@@ -433,12 +433,12 @@ def test_dense_cluster_inside_a_few_tiles(gpu_ctx):
     assert g["stats"]["hit_pixels"] > 50 and g["stats"]["shadow_rays"] > 50
 
 
-def _random_scene(seed):
+def _random_scene(seed, lo=1, hi=90):
     """Adversarial mix for the culling bounds: radii over 5 decades, spheres around and behind the
     camera, slivers, triangles whose plane passes through the world origin (degenerate edge planes:
-    infinite bound), lights of both kinds, one of them inside the geometry."""
+    infinite bound), lights of both kinds, one of them inside the geometry.  lo / hi: primitives per type."""
     rng = np.random.default_rng(seed)
-    ns, nt = int(rng.integers(1, 90)), int(rng.integers(1, 90))
+    ns, nt = int(rng.integers(lo, hi)), int(rng.integers(lo, hi))
     c = rng.uniform(-30, 30, (ns, 3))
     r = 10.0 ** rng.uniform(-3, 1.5, ns)
     sp = np.concatenate([c, r[:, None]], axis=1).astype(np.float32)
@@ -458,6 +458,38 @@ def _random_scene(seed):
     cam = {"look_from": tuple(rng.uniform(-20, 20, 3)), "look_at": tuple(rng.uniform(-5, 5, 3)), "up": (0.1, 1.0, 0.05),
            "vfov": float(rng.uniform(15, 100))}
     return scenes.SceneSpec(f"random{seed}", sp, sphere_obj, tv, tri_obj, kind, rgb, lights, cam)
+
+
+@pytest.mark.parametrize("team", [0, 1, 4, 5])
+@pytest.mark.parametrize("seed,shift", [(1271, 1e5), (1362, 1e5), (1270, 1e5), (7, 0.0), (8, 1e3)])
+def test_many_cluster_scenes_depth_bounds_and_teams(gpu_ctx, kernel_mode, seed, shift, team):
+    """Scenes of thousands of primitives (dozens of clusters per type), also far from the world origin, where rounding
+    widens every cone: the tile-culling kernel -- hierarchy walk, depth bound of a covered tile, plane and
+    screen-space edge refinement of crowded leaves -- against the brute-force kernel, bit for bit, with one wave per
+    tile and with teams of four dealing leaves or lights.  Seeds 1271 / 1362 / 1270 at 1e5 units are the ones with which
+    tools/stress_parity.py found the plane test's bound on |n.u| wrong for a normal inside the cone."""
+    if kernel_mode != "cull":
+        pytest.skip("one comparison: brute force against the tile-culling kernel")
+    sys_path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools")
+    import sys
+    if sys_path not in sys.path:
+        sys.path.insert(0, sys_path)
+    from stress_common import moved
+    spec = moved(_random_scene(seed, 200, 4000), shift, 1.0)
+    W, H = 184, 148
+    gpu_ctx.upload(spec.flatten())
+    cam = spec.cam12(W / H)
+    gpu_ctx.set_cull(0)
+    ref = gpu_ctx.render(cam, W, H)
+    gpu_ctx.set_cull(2)
+    gpu_ctx.set_cull_team(team)
+    try:
+        g = gpu_ctx.render(cam, W, H)
+    finally:
+        gpu_ctx.set_cull_team(0)
+    for k in ("id", "t", "rgb"):
+        assert np.array_equal(g[k], ref[k], equal_nan=True), (k, int((g[k] != ref[k]).sum()))
+    assert_stats_parity(g["stats"], ref["stats"])
 
 
 @pytest.mark.parametrize("seed", range(12))

@@ -1,9 +1,12 @@
 """Stress run: many random scenes, every culling kernel against the brute-force kernel, bit for bit.
-usage: python tools/stress_parity.py <first_seed> <count> [small|large|both] [shift [scale [wild]]]
+usage: python tools/stress_parity.py <first_seed> <count> [small|large|both|huge] [shift [scale [wild]]]
+huge: 200 to 4000 primitives per type (dozens of clusters: hierarchy walks, depth bounds, teams dealing leaves).
 wild (any sixth argument): per seed, also one of: extreme field of view, camera very far or very near, radii over
 eight decades, degenerate triangles (repeated or collinear vertices), a NaN or an infinity in the geometry.
 shift / scale: the whole scene (geometry, point lights, camera) is scaled and then moved by shift * (0.6, -0.4, 1)
--- far from the world origin fp32 positions get coarse, which is what the culling margins have to survive."""
+-- far from the world origin fp32 positions get coarse, which is what the culling margins have to survive.
+Environment: MRT_CULL_TEAM=4 renders every large scene with teams of four waves per tile (mrt_cull.hip) dealing leaves,
+MRT_CULL_TEAM=5 with teams dealing lights."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, os.path.join(ROOT, "tools"))
@@ -23,10 +26,11 @@ ctx = capi.Context(0)
 bad = 0
 t0 = time.time()
 for seed in range(first, first + count):
-    for kind in ("small", "large"):
-        if which not in (kind, "both"):
+    for kind in ("small", "large", "huge"):
+        if which not in (kind, "both") or (kind == "huge" and which != "huge"):
             continue
-        spec = T._random_small_scene(seed) if kind == "small" else T._random_scene(seed)
+        spec = T._random_small_scene(seed) if kind == "small" else (T._random_scene(seed) if kind == "large" else
+                                                                      T._random_scene(seed, 200, 4000))
         if wild:
             spec = make_wild(spec, seed)
         spec = moved(spec, shift, scale)
@@ -53,7 +57,7 @@ for seed in range(first, first + count):
                 bad += 1
                 print("MISMATCH seed", seed, kind, "brute force vs ORACLE", W, H, spp,
                       {k: int((~((ref[k] == r[k]) | (np.isnan(ref[k]) & np.isnan(r[k])))).sum()) for k in ("id", "t", "rgb")}, flush=True)
-        for mode in ((5, 2) if kind == "small" else (2, 4)):
+        for mode in ((5, 2) if kind == "small" else (2,)):
             ctx.set_cull(mode); g = ctx.render(cam, W, H, spp=spp, rank=part[0], num_ranks=part[1], strip_rows=part[2])
             ok = all(np.array_equal(g[k], ref[k], equal_nan=True) for k in ("id", "t", "rgb")) and \
                  all(g["stats"][k] == ref["stats"][k] for k in ("primary_rays", "shadow_rays", "hit_pixels", "occluded"))
