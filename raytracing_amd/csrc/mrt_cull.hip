@@ -67,7 +67,7 @@ template <> struct CVec<4> { typedef float f __attribute__((ext_vector_type(4)))
 // in light order (core/light.cuh:171-173; fp32 addition does not associate), so a member does not add up its own
 // lights: it leaves each light's contribution in LDS, and member 0 folds them in order, 32 lights at a time.
 #ifndef MRT_CULL_TEAM_WAVES
-#define MRT_CULL_TEAM_WAVES 7
+#define MRT_CULL_TEAM_WAVES 1 // 7 fits the team kernels into 72 registers only by spilling to scratch (C4 3 % faster, 0.3 GB of extra writes per frame): left alone
 #endif
 template <bool HIER, int P, bool MULTI, int NW, bool LSPLIT = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NW > 1 && !MULTI ? MRT_CULL_TEAM_WAVES : 1, 8)))
