@@ -825,13 +825,21 @@ const Rccl *rccl(std::string *why)
   static Rccl R;
   static std::once_flag once;
   std::call_once(once, [] {
+    // MRT_RCCL_LIB names a library outright.  Otherwise an RCCL the process has loaded already is preferred (torch
+    // ships one and registers it as "librccl.so": sharing it is what a second torch communicator would do, whereas a
+    // second RCCL instance beside it doubles the proxy threads and buffers), then the ROCm installation's.
     const char *env = getenv("MRT_RCCL_LIB");
-    const char *names[] = {env, "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
-    for (const char *n : names) {
-      if (!n || !*n) continue;
-      R.lib = dlopen(n, RTLD_NOW | RTLD_LOCAL);
-      if (R.lib) break;
-      R.err = dlerror();
+    if (env && *env) {
+      R.lib = dlopen(env, RTLD_NOW | RTLD_LOCAL);
+      if (!R.lib) R.err = dlerror();
+    } else {
+      for (const char *n : {"librccl.so", "librccl.so.1"})
+        if (!R.lib) R.lib = dlopen(n, RTLD_NOW | RTLD_LOCAL | RTLD_NOLOAD);
+      for (const char *n : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+        if (R.lib) break;
+        R.lib = dlopen(n, RTLD_NOW | RTLD_LOCAL);
+        if (!R.lib) R.err = dlerror();
+      }
     }
     if (!R.lib) { R.err = "cannot open RCCL (librccl.so.1): " + R.err; return; }
     bool ok = true;

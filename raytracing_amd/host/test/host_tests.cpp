@@ -117,12 +117,54 @@ static void test_default_scene_frame(rt::Renderer &gpu)
   EXPECT_TRUE(diff_rgb > 1000);
 }
 
+// rt::MultiGpuRenderer over the GPUs this box has (one here): the same frame as rt::Renderer, byte for byte; and
+// the ROCm installation's RCCL opened, a communicator made and destroyed, from a process without torch
+static void test_multi_gpu_renderer(rt::Renderer &gpu)
+{
+  std::printf("[ RUN      ] TestRender.MultiGpuRendererMatchesRenderer\n");
+  const std::size_t W = 320, H = 200;
+  auto viewport = rt::config::make_viewport(float(W) / float(H));
+  auto scene = rt::config::make_default_scene();
+  rt::ImageBuffer one(W, H), many(W, H);
+  gpu.upload(rt::make_view(scene.objects), rt::make_view(scene.lights));
+  const mrt_stats s1 = gpu.render(viewport, one, 1, 0);
+  int ngpu = 0;
+  checkRtErrors(mrt_device_count(&ngpu));
+  rt::MultiGpuRenderer group(ngpu, 16);
+  group.upload(rt::make_view(scene.objects), rt::make_view(scene.lights));
+  const mrt_stats sn = group.render(viewport, many, 1, 0);
+  long long diff = 0;
+  for (std::size_t i = 0; i < W * H; ++i)
+    diff += (one.ids()[i] != many.ids()[i]) + (one.ts()[i] != many.ts()[i]) + (one.buffer()[i].x != many.buffer()[i].x) +
+            (one.buffer()[i].y != many.buffer()[i].y) + (one.buffer()[i].z != many.buffer()[i].z);
+  EXPECT_EQ(diff, 0);
+  EXPECT_EQ(sn.shadow_rays, s1.shadow_rays);
+  EXPECT_EQ(sn.hit_pixels, s1.hit_pixels);
+
+  std::printf("[ RUN      ] TestRender.LocalCommunicatorOfOne\n");
+  mrt_ctx *c = gpu.ctx();
+  mrt_comm *comm = nullptr;
+  EXPECT_EQ(mrt_comm_create_local(&c, 1, &comm), 0);
+  EXPECT_TRUE(comm != nullptr);
+  mrt_camera cam = viewport.to_abi();
+  mrt_render_params p{};
+  p.width = int(W); p.height = int(H); p.spp = 1; p.max_depth = 0;
+  p.part = rt::make_strip_partition(0, 1, 8);
+  rt::ImageBuffer again(W, H);
+  EXPECT_EQ(mrt_render_multi(&c, &comm, 1, &cam, &p, &again.buffer()[0].x, again.ids(), again.ts(), nullptr), 0);
+  long long d2 = 0;
+  for (std::size_t i = 0; i < W * H; ++i) d2 += (one.ids()[i] != again.ids()[i]) + (one.buffer()[i].y != again.buffer()[i].y);
+  EXPECT_EQ(d2, 0);
+  EXPECT_EQ(mrt_comm_destroy(comm), 0);
+}
+
 int main()
 {
   rt::Renderer gpu(0);
   test_sphere(gpu);
   test_triangle(gpu);
   test_default_scene_frame(gpu);
+  test_multi_gpu_renderer(gpu);
   std::printf("%d checks, %d failed\n", g_checks, g_failed);
   return g_failed ? 1 : 0;
 }
