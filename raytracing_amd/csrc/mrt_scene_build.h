@@ -87,6 +87,13 @@ inline void kd_split(uint32_t *idx, size_t lo, size_t hi, const float *c)
   kd_split(idx, mid, hi, c);
 }
 
+// MRT_LOOSE_FACTOR (ablation; 0 = keep loose primitives where the kd order puts them)
+inline float loose_factor()
+{
+  static const float f = [] { const char *e = getenv("MRT_LOOSE_FACTOR"); return e ? (float)atof(e) : 8.0f; }();
+  return f;
+}
+
 template <class BoundFn> inline void kd_order(size_t n, BoundFn bound, std::vector<uint32_t> &order)
 {
   order.clear();
@@ -99,7 +106,24 @@ template <class BoundFn> inline void kd_order(size_t n, BoundFn bound, std::vect
     if (std::isfinite(b[3]) && std::isfinite(b[0]) && std::isfinite(b[1]) && std::isfinite(b[2])) order.push_back((uint32_t)i);
     else unbounded.push_back((uint32_t)i);
   }
-  if (n > 64) kd_split(order.data(), 0, order.size(), c.data());
+  // Primitives with a far larger bound than the rest (the long wedges the reference's edge planes accept for some
+  // triangles: 6 395 of the 1M-triangle terrain) get clusters of their own behind the regular ones: inside a regular
+  // cluster a single one of them inflates the cluster's ball until every tile opens it.  "Far larger" = more than
+  // loose_factor() times the median radius.
+  std::vector<uint32_t> loose;
+  if (order.size() > 128 && loose_factor() > 0.0f) {
+    std::vector<float> radii(order.size());
+    for (size_t i = 0; i < order.size(); ++i) radii[i] = c[4 * order[i] + 3];
+    std::nth_element(radii.begin(), radii.begin() + radii.size() / 2, radii.end());
+    const float limit = loose_factor() * radii[radii.size() / 2];
+    std::vector<uint32_t> regular;
+    regular.reserve(order.size());
+    for (uint32_t i : order) (c[4 * i + 3] > limit ? loose : regular).push_back(i);
+    order.swap(regular);
+  }
+  if (order.size() > 64) kd_split(order.data(), 0, order.size(), c.data());
+  if (loose.size() > 64) kd_split(loose.data(), 0, loose.size(), c.data());
+  order.insert(order.end(), loose.begin(), loose.end());
   order.insert(order.end(), unbounded.begin(), unbounded.end());
 }
 
