@@ -51,7 +51,7 @@ def main():
     keys, inv, counts = np.unique(simd_key, return_inverse=True, return_counts=True)
     per_simd_end = np.zeros(len(keys)); np.maximum.at(per_simd_end, inv, end)
     per_simd_life = np.zeros(len(keys)); np.add.at(per_simd_life, inv, life)
-    q = lambda a: [int(x) for x in np.percentile(a, [0, 10, 50, 90, 99, 100])]
+    q = lambda a: [int(x) for x in np.percentile(a, [0, 10, 50, 90, 99, 100])] if len(a) else [0] * 6
     prof = []
     for k in range(24):
         mid = (k + 0.5) * span / 24

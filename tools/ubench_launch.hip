@@ -15,6 +15,26 @@ struct Big { float f[960]; };
 __global__ void empty_kernel(int *p) { if (p && threadIdx.x == 12345) *p = 1; }
 __global__ void empty_big_kernel(Big b, int *p) { if (p && threadIdx.x == 12345) *p = (int)b.f[5]; }
 
+// every wave reads 12 x 64 floats (lanes below `live` only) from the argument block or from a device buffer and ends
+__global__ void read_args_kernel(Big b, int live, float *out)
+{
+  const int lane = threadIdx.x & 63;
+  float acc = 0.f;
+  if (lane < live)
+#pragma unroll
+    for (int i = 0; i < 12; ++i) acc += b.f[i * 64 + lane];
+  if (acc == 12345.f) *out = acc;
+}
+__global__ void read_buf_kernel(const float *__restrict__ b, int live, float *out)
+{
+  const int lane = threadIdx.x & 63;
+  float acc = 0.f;
+  if (lane < live)
+#pragma unroll
+    for (int i = 0; i < 12; ++i) acc += b[i * 64 + lane];
+  if (acc == 12345.f) *out = acc;
+}
+
 typedef float nfloat2 __attribute__((ext_vector_type(2)));
 typedef float nfloat4 __attribute__((ext_vector_type(4)));
 
@@ -85,6 +105,15 @@ int main()
   printf("empty kernels, 1 wave per workgroup, by grid size:\n");
   for (int n : {1, 256, 1024, 2048, 4096, 8192, 16384, 32768, 65536})
     printf("  %6d workgroups: %.2f us\n", n, time_us([&] { hipLaunchKernelGGL(empty_kernel, dim3(n), dim3(64), 0, 0, (int *)nullptr); }));
+  printf("16200 one-wave workgroups that read 12 floats per lane and end:\n");
+  {
+    float *buf; CK(hipMalloc(&buf, sizeof(Big))); CK(hipMemcpy(buf, &big, sizeof(Big), hipMemcpyHostToDevice));
+    dim3 g(120, 135);
+    for (int live : {10, 64})
+      printf("  %2d lanes live: from the argument block %.2f us, from a device buffer %.2f us\n", live,
+             time_us([&] { hipLaunchKernelGGL(read_args_kernel, g, dim3(64), 0, 0, big, live, (float *)rgb); }),
+             time_us([&] { hipLaunchKernelGGL(read_buf_kernel, g, dim3(64), 0, 0, (const float *)buf, live, (float *)rgb); }));
+  }
   printf("store-only kernels (41.5 MB per launch):\n");
 #define CASE(P, NT, WPW, T) { dim3 g((W / (8 * P * T) + WPW - 1) / WPW, 135); \
     float us = time_us([&] { hipLaunchKernelGGL((store_kernel<P, NT>), g, dim3(64 * WPW), 0, 0, rgb, id, t, W, H, T); }); \
