@@ -231,7 +231,8 @@ def main():
     gather = "none"
     if world > 1:
         gather = "torch.distributed point-to-point (" + backend + ")"
-        if backend == "nccl" and os.environ.get("MRT_BENCH_GATHER", "capi") == "capi":
+        want = os.environ.get("MRT_BENCH_GATHER", "capi")  # "torch": skip; "capi-force": try even in a gloo rehearsal
+        if (backend == "nccl" and want == "capi") or want == "capi-force":
             from raytracing_amd import capi
             uid = [None]
             ok = 1
