@@ -79,6 +79,14 @@ __device__ __forceinline__ float abs1(float x, float y, float z) { return fabsf(
 #ifndef MRT_ABL
 #define MRT_ABL 0
 #endif
+// Phase cuts (make variant DEFS=-DMRT_CUT=n; never the product library): tiles with candidates end after phase n --
+// 8 rays set up, 9 closest hits, 10 hit records, 11 shadow bundle, 12 shadow candidates, 13 shadow rays, 14 shading --
+// without storing; what the phase computed feeds a condition that is never true, so it is not optimised away.  The
+// counters of two neighbouring cuts differ by one phase (tools/phase_counters.sh, profiles/*_phase_counters.json).
+#ifndef MRT_CUT
+#define MRT_CUT 0
+#endif
+#define MRT_CUT_AT(k, expr) do { if (MRT_CUT == (k)) { if ((expr) == 1234.5f) A.rgb[0] = 1.0f; return; } } while (0)
 #ifndef MRT_SMALL_BANDS_LOG2
 #define MRT_SMALL_BANDS_LOG2 0 // 3: rows of tiles launched interleaved from 8 bands of the frame (measured: slower)
 #endif
@@ -101,26 +109,20 @@ __device__ unsigned long long g_timeline[TL_WORDS * TL_MAX_WAVES];
 // segment, one memory round trip after launch.
 //
 // SmallHot: what a wave needs before anything has arrived from memory.  These are the FIRST kernel arguments,
-// 14 dwords, and gfx950 loads them into SGPRs while it launches the wave (kernarg preload; Makefile:
-// -mllvm -amdgpu-kernarg-preload-count=14 for this file): the wave can issue the loads of its primitive's
-// parameters and of its u / v table entries, and compute its tiles' cones, in its first cycles instead of after a
-// scalar round trip (measured: the prologue was 3000 of a sky tile's 6200 cycles).  The camera is here in the form
-// the CULLING arithmetic uses (up_left - origin folded, approximate arithmetic is fine there); the rays are computed
-// from the exact twelve camera floats in SmallArgs, which have arrived by then.
+// 5 dwords, and gfx950 loads them into SGPRs while it launches the wave (kernarg preload; Makefile:
+// -mllvm -amdgpu-kernarg-preload-count=5 for this file): the wave can issue the loads of its primitive's culling
+// parameters and of its u / v table entries in its first cycles instead of after a scalar round trip (measured:
+// the prologue was 3000 of a sky tile's 6200 cycles).
 struct SmallHot {
-  float bx, by, bz;  // up_left - origin
-  float hx, hy, hz;  // horizontal
-  float vx, vy, vz;  // vertical
   uint32_t wh;       // (W - 1) | (H - 1) << 16
-  float cone_ext;    // RenderArgs::cone_ext; negative: the frame is strip-partitioned (rows need the strip rule)
+  float part_flag;   // negative: the frame is strip-partitioned (rows need the strip rule, which reads SmallArgs)
   uint32_t meta;     // ns | nt << 8 | rows of tiles per band << 16 (row interleave, below)
   const float *utab; // u = col / W table; the v = row / H table follows at utab + uv_table_stride(W)
 };
-static_assert(sizeof(SmallHot) == 14 * 4, "the preloaded arguments are 14 dwords");
+static_assert(sizeof(SmallHot) == 6 * 4, "the preloaded arguments are 5 dwords (+ 1 of alignment)");
 
 template <int P, bool MULTI, int TPW>
-__device__ __forceinline__ void render_small_body(float qbx, float qby, float qbz, float qhx, float qhy, float qhz,
-                                                  float qvx, float qvy, float qvz, uint32_t wh, float cone_ext_s,
+__device__ __forceinline__ void render_small_body(uint32_t wh, float cone_ext_s,
                                                   uint32_t meta, const float *utab_hot, const SmallArgs &S)
 {
   const RenderArgs &A = S.A;
@@ -163,7 +165,7 @@ __device__ __forceinline__ void render_small_body(float qbx, float qby, float qb
   for (int i = 0; i < 12; ++i) cp[i] = 0.0f;
   if (own_s) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) cp[i] = S.prm[i][lane];
+    for (int i = 0; i < 4; ++i) cp[i] = S.prm[9 + i][lane]; // screen rectangle: u from, to, v from, to
   } else if (own_t) {
 #pragma unroll
     for (int i = 0; i < 12; ++i) cp[i] = S.prm[i][lane];
@@ -185,10 +187,8 @@ __device__ __forceinline__ void render_small_body(float qbx, float qby, float qb
   // ---- cones around the tiles' rays, each padded by one pixel on every side (covers the 121-spp offsets): every
   //      ray of a padded tile is its centre ray plus an offset of norm <= cone_ext (launcher); which primitives
   //      can any ray of tile j hit? ----
-  const float cone_ext = fabsf(cone_ext_s);
   const float rw = fast_rcp(float(W)), rh = fast_rcp(float(H)); // bound arithmetic: approximate is fine
   const float vm = (float(grow0) + 3.5f) * rh;
-  const float rbx = qbx + vm * qvx, rby = qby + vm * qvy, rbz = qbz + vm * qvz;
   unsigned long long pmask[TPW];
 #pragma unroll
   for (int j = 0; j < TPW; ++j) {
@@ -197,14 +197,8 @@ __device__ __forceinline__ void render_small_body(float qbx, float qby, float qb
       const float um = (float((tile_x0 + j) * TW) + 0.5f * float(TW - 1)) * rw;
       bool pass = false;
       if (own_s) {
-        float cax = rbx + um * qhx, cay = rby + um * qhy, caz = rbz + um * qhz;
-        const float inv = fast_rsq(dot3(cax, cay, caz, cax, cay, caz));
-        cax *= inv; cay *= inv; caz *= inv;
-        float sinT = cone_ext * inv * (1.0f + 1e-4f) + 1e-6f;
-        float cosT = fast_sqrt(fmaxf(1.0f - sinT * sinT, 0.0f)) * (1.0f - 1e-5f) - 1e-6f;
-        // a cone of 90 degrees or more (or a NaN camera) cannot cull: cos = -1 makes every ball pass
-        if (!(sinT < 0.99f) || !(cosT > 0.0f)) { cosT = -1.0f; sinT = 0.0f; }
-        pass = ball_may_touch_cone(cp[0], cp[1], cp[2], cp[3], cax, cay, caz, cosT, sinT);
+        // the sphere's screen rectangle of tile centres (launcher: small_primary_functions); NaN never culls
+        pass = !(um < cp[0]) & !(um > cp[1]) & !(vm < cp[2]) & !(vm > cp[3]);
       } else if (own_t) {
         bool cull = false;
 #pragma unroll
@@ -233,7 +227,11 @@ __device__ __forceinline__ void render_small_body(float qbx, float qby, float qb
   float e0 = 0.0f, e1 = 0.0f, e2 = 0.0f, e3 = 0.0f;    // sphere: o - c, |o - c|^2 - r^2;  triangle: e0 = k - n.o
   float rr = 0.0f;                                     // sphere: r^2
   int pobj = 0;
-  if (own_s) {
+  unsigned long long any_candidates = 0ull; // a wave whose tiles are all sky needs none of this (70 % of the default frame's)
+#pragma unroll
+  for (int j = 0; j < TPW; ++j) any_candidates |= pmask[j];
+  if (any_candidates == 0ull) {
+  } else if (own_s) {
     e0 = S.prm[4][lane]; e1 = S.prm[5][lane]; e2 = S.prm[6][lane]; e3 = S.prm[7][lane];
     pobj = __float_as_int(S.prm[8][lane]);
     bx = sc.sph_cx[lane]; by = sc.sph_cy[lane]; bz = sc.sph_cz[lane]; brad = sc.sph_r[lane];
@@ -339,6 +337,7 @@ __device__ __forceinline__ void render_small_body(float qbx, float qby, float qb
     }
 
     TL_MARK(8); // rays set up
+    MRT_CUT_AT(8, dx[0] + dy[P - 1] + dz[0] + aa[P - 1]);
     // ---- closest hit over the surviving spheres: src/main.cu:60-77, core/sphere.cuh:32-73, [0.01, inf] ----
     {
       unsigned long long mask = primary_mask & smask_all;
@@ -394,6 +393,7 @@ __device__ __forceinline__ void render_small_body(float qbx, float qby, float qb
     }
 
     TL_MARK(9); // closest hits found
+    MRT_CUT_AT(9, best_t[0] + best_t[P - 1] + float(best_obj[0] + best_k[P - 1]));
     // ---- hit records of the winners (core/sphere.cuh:45-47, core/triangle.cuh:96-97); the winner's centre /
     //      plane normal comes from the owning lane's registers ----
     bool have_hit[P], any_hit_lane = false;
@@ -426,6 +426,7 @@ __device__ __forceinline__ void render_small_body(float qbx, float qby, float qb
     }
 
     TL_MARK(10); // hit records
+    MRT_CUT_AT(10, hpx[0] + hpy[P - 1] + hpz[0] + hnx[P - 1] + hny[0] + hnz[P - 1]);
     // ---- shadow rays + direct light: core/light.cuh:135-178 ----
     float lr[P], lg[P], lb[P];
     bool have_light[P];
@@ -468,6 +469,7 @@ __device__ __forceinline__ void render_small_body(float qbx, float qby, float qb
       // One light.  POINT is a compile-time switch: for a directional light the shadow ray direction, its
       // squared length and the light's normal are wave-uniform scalars, for a point light per-pixel registers.
       TL_MARK(11); // bundle
+      MRT_CUT_AT(11, B.rho + reff_shadow + Pmax + B.mx);
       auto shade_light = [&](auto point_tag, int li, float lvx, float lvy, float lvz) {
         constexpr bool POINT = decltype(point_tag)::value;
         constexpr int Q = POINT ? P : 1;
@@ -526,6 +528,7 @@ __device__ __forceinline__ void render_small_body(float qbx, float qby, float qb
           }
           const unsigned long long shadow_mask = __ballot(pass);
           TL_MARK(12); // shadow candidates known (last light)
+          MRT_CUT_AT(12, float(shadow_mask & 0xffffffull));
           n_clusters++; n_exact += __popcll(shadow_mask);
           unsigned long long mask = shadow_mask & smask_all;
           bool go = true;
@@ -573,6 +576,7 @@ __device__ __forceinline__ void render_small_body(float qbx, float qby, float qb
         }
 
         TL_MARK(13); // shadow rays traced (last light)
+        MRT_CUT_AT(13, float(open[0]) + float(open[P - 1]) + float(need[0]));
         const float lcr = sc.light_rgb[3 * li], lcg = sc.light_rgb[3 * li + 1], lcb = sc.light_rgb[3 * li + 2];
 #pragma unroll
         for (int p = 0; p < P; ++p) {
@@ -604,6 +608,7 @@ __device__ __forceinline__ void render_small_body(float qbx, float qby, float qb
     }
 
     TL_MARK(14); // lights done
+    if (MRT_CUT >= 12 && MRT_CUT <= 14) { if (lr[0] + lg[P - 1] + lb[0] + float(have_light[P - 1]) == 1234.5f) A.rgb[0] = 1.0f; return; }
     // ---- combine: src/main.cu:91-104 with MAX_RECURSION_DEPTH = 0 ----
 #pragma unroll
     for (int p = 0; p < P; ++p) {
@@ -698,10 +703,9 @@ __device__ __forceinline__ void render_small_body(float qbx, float qby, float qb
 #endif
 template <int P, bool MULTI>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(P == 2 && !MULTI ? MRT_SMALL_WAVES : 1, 8)))
-void render_small_kernel(float qbx, float qby, float qbz, float qhx, float qhy, float qhz, float qvx, float qvy, float qvz,
-                         uint32_t wh, float cone_ext_s, uint32_t meta, const float *utab, SmallArgs S)
+void render_small_kernel(uint32_t wh, float cone_ext_s, uint32_t meta, const float *utab, SmallArgs S)
 {
-  render_small_body<P, MULTI, MRT_SMALL_TPW_DEFAULT>(qbx, qby, qbz, qhx, qhy, qhz, qvx, qvy, qvz, wh, cone_ext_s, meta, utab, S);
+  render_small_body<P, MULTI, MRT_SMALL_TPW_DEFAULT>(wh, cone_ext_s, meta, utab, S);
 }
 
 // ---- primary-ray functions (host, double; per render) ---------------------------------------------------
@@ -734,6 +738,45 @@ static void small_primary_functions(const RenderArgs &A, const SmallHost &hs, do
   auto n1f = [](const double *a) { return std::fabs(a[0]) + std::fabs(a[1]) + std::fabs(a[2]); };
   const double o1 = n1f(o);
   const double cam_delta = 2.0 * camera_rounding(A.cam);
+  // Spheres, primary rays: the SCREEN RECTANGLE of the tile centres whose (padded) tile can hold a ray that touches
+  // the sphere -- four compares per tile in the kernel instead of a cone test.  A ray d hits the ball (w = c - o,
+  // radius R) iff (d.w)^2 >= |d|^2 (|w|^2 - R^2); with d(u, v) = base + u h + v vv that is a quadratic S(u, v) >= 0,
+  // for a ball in front of the camera the inside of an ellipse, whose extent in u is where max_v S(u, v) = 0 (and
+  // likewise in v).  R = the cone test's cull radius plus what the rounding of the ray directions (camera_rounding)
+  // can move a ray at the ball's distance.  Anything else -- camera inside the ball, a ball reaching behind the
+  // camera (hyperbola), a degenerate camera, NaN -- gets the rectangle that holds every tile.
+  {
+    double nrm[3] = {h[1] * vv[2] - h[2] * vv[1], h[2] * vv[0] - h[0] * vv[2], h[0] * vv[1] - h[1] * vv[0]};
+    const double nl = std::sqrt(dot(nrm, nrm));
+    const double plane_dist = nl > 0.0 ? std::fabs(dot(base, nrm)) / nl : 0.0; // every ray is at least this long
+    for (int i = 0; i < ns; ++i) {
+      float lo_u = -INFINITY, hi_u = INFINITY, lo_v = -INFINITY, hi_v = INFINITY;
+      const double w[3] = {prm[0][i], prm[1][i], prm[2][i]};
+      const double L = std::sqrt(dot(w, w));
+      if (plane_dist > 1e-30 && std::isfinite(L) && std::isfinite((double)prm[3][i])) {
+        const double R = ((double)prm[3][i] + L * (cam_delta / plane_dist) * 1.01) * (1.0 + 1e-6) + 1e-6 * L;
+        const double K = L * L - R * R;
+        auto q = [&](const double *x, const double *y) { return dot(w, x) * dot(w, y) - K * dot(x, y); };
+        const double a11 = q(h, h), a12 = q(h, vv), a22 = q(vv, vv), b1 = q(base, h), b2 = q(base, vv), c0 = q(base, base);
+        const double det = a11 * a22 - a12 * a12;
+        if (K > 0.0 && a11 < 0.0 && a22 < 0.0 && det > 1e-9 * a11 * a22) {
+          const double uc = (a12 * b2 - a22 * b1) / det, vc = (a12 * b1 - a11 * b2) / det; // the ellipse's centre
+          const double dc[3] = {base[0] + uc * h[0] + vc * vv[0], base[1] + uc * h[1] + vc * vv[1], base[2] + uc * h[2] + vc * vv[2]};
+          const double Au = a11 - a12 * a12 / a22, Bu = b1 - a12 * b2 / a22, Cu = c0 - b2 * b2 / a22;
+          const double Av = a22 - a12 * a12 / a11, Bv = b2 - a12 * b1 / a11, Cv = c0 - b1 * b1 / a11;
+          const double du = Bu * Bu - Au * Cu, dv = Bv * Bv - Av * Cv;
+          if (dot(w, dc) > 0.0 && Au < 0.0 && Av < 0.0 && du > 0.0 && dv > 0.0) { // in front; real extents
+            const double su = std::sqrt(du) / -Au, sv = std::sqrt(dv) / -Av, mu = -Bu / Au, mv = -Bv / Av;
+            const double pad_u = hu + 1e-5 * (1.0 + std::fabs(mu) + su), pad_v = hv + 1e-5 * (1.0 + std::fabs(mv) + sv);
+            lo_u = std::nextafter((float)(mu - su - pad_u), -INFINITY); hi_u = std::nextafter((float)(mu + su + pad_u), INFINITY);
+            lo_v = std::nextafter((float)(mv - sv - pad_v), -INFINITY); hi_v = std::nextafter((float)(mv + sv + pad_v), INFINITY);
+            if (!(lo_u <= hi_u) || !(lo_v <= hi_v)) { lo_u = lo_v = -INFINITY; hi_u = hi_v = INFINITY; }
+          }
+        }
+      }
+      prm[9][i] = lo_u; prm[10][i] = hi_u; prm[11][i] = lo_v; prm[12][i] = hi_v;
+    }
+  }
   for (int j = 0; j < nt; ++j) {
     const float *q = tri16 + 16 * j;
     float (*pri)[64] = prm;
@@ -815,7 +858,6 @@ static hipError_t launch_small(const RenderArgs &in, const SmallHost &hs, hipStr
   // the arguments the hardware preloads (SmallHot): camera in culling form, frame size, cone extent (its sign flags a
   // strip partition), the u table, tiles per wave and primitive counts
   const int tpw = small_tiles_per_wave();
-  const DevCamera &c = A.cam;
   const bool partitioned = !(A.nranks == 1 && A.rank == 0);
   const float cone_s = partitioned ? -A.cone_ext : A.cone_ext;
   const uint32_t wh = (uint32_t)(A.W - 1) | ((uint32_t)(A.H - 1) << 16);
@@ -826,11 +868,9 @@ static hipError_t launch_small(const RenderArgs &in, const SmallHost &hs, hipStr
   // groups of four (measured 19.4 against 19.9 us on the default frame)
   const dim3 grid((tiles_x + tpw - 1) / tpw, band_rows * BANDS);
   if (A.spp > 1)
-    hipLaunchKernelGGL((render_small_kernel<P, true>), grid, dim3(64), 0, stream, c.ux - c.ox, c.uy - c.oy, c.uz - c.oz,
-                       c.hx, c.hy, c.hz, c.vx, c.vy, c.vz, wh, cone_s, meta, A.utab, S);
+    hipLaunchKernelGGL((render_small_kernel<P, true>), grid, dim3(64), 0, stream, wh, cone_s, meta, A.utab, S);
   else
-    hipLaunchKernelGGL((render_small_kernel<P, false>), grid, dim3(64), 0, stream, c.ux - c.ox, c.uy - c.oy, c.uz - c.oz,
-                       c.hx, c.hy, c.hz, c.vx, c.vy, c.vz, wh, cone_s, meta, A.utab, S);
+    hipLaunchKernelGGL((render_small_kernel<P, false>), grid, dim3(64), 0, stream, wh, cone_s, meta, A.utab, S);
   return hipGetLastError();
 }
 
