@@ -187,7 +187,7 @@ __device__ __forceinline__ void render_bounce_body(const Args &S)
     bool pass = false;
     if (SMALL) { // lane = primitive (spheres first): cone test / screen-space edge functions, as in mrt_small.hip
       if (lane < ns) {
-        pass = ball_may_touch_cone(prm_of(S, 0, lane), prm_of(S, 1, lane), prm_of(S, 2, lane), prm_of(S, 3, lane), cax,
+        pass = ball_may_touch_cone(prm_of(S, 9, lane), prm_of(S, 10, lane), prm_of(S, 11, lane), prm_of(S, 12, lane), cax,
                                    cay, caz, cosT, sinT);
       } else if (lane < ns + nt) {
         bool cull = false;
@@ -821,7 +821,7 @@ __global__ __launch_bounds__(256) void bounce_weigh_kernel(SmallArgs S, uint32_t
     float cosT = fast_sqrt(fmaxf(1.0f - sinT * sinT, 0.0f)) * (1.0f - 1e-5f) - 1e-6f;
     if (!(sinT < 0.99f) || !(cosT > 0.0f)) { cosT = -1.0f; sinT = 0.0f; }
     if (lane < ns) {
-      pass = ball_may_touch_cone(S.prm[0][lane], S.prm[1][lane], S.prm[2][lane], S.prm[3][lane], ax, ay, az, cosT, sinT);
+      pass = ball_may_touch_cone(S.prm[9][lane], S.prm[10][lane], S.prm[11][lane], S.prm[12][lane], ax, ay, az, cosT, sinT);
     } else if (lane < ns + nt) {
       bool cull = false;
 #pragma unroll

@@ -160,16 +160,12 @@ __device__ __forceinline__ void render_small_body(uint32_t wh, float cone_ext_s,
   // the primitive this lane owns (spheres first, then triangles): culling parameters, straight from the argument
   // segment (its address is in SGPRs from the start)
   const bool own_s = lane < ns, own_t = (lane >= ns) && (lane < ns + nt);
+  // fields 0..11 of the lane's column, whatever the lane owns (a sphere uses 0..3: its screen rectangle; a triangle
+  // all twelve: four edge functions; lanes that own nothing read their column too and ignore it): no branches, and
+  // nothing to initialise
   float cp[12];
 #pragma unroll
-  for (int i = 0; i < 12; ++i) cp[i] = 0.0f;
-  if (own_s) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) cp[i] = S.prm[9 + i][lane]; // screen rectangle: u from, to, v from, to
-  } else if (own_t) {
-#pragma unroll
-    for (int i = 0; i < 12; ++i) cp[i] = S.prm[i][lane];
-  }
+  for (int i = 0; i < 12; ++i) cp[i] = S.prm[i][lane];
   // rows: without a strip partition local row = frame row; with one, the strip rule (needs arguments from memory)
   int grow0 = lrow0;
   if (cone_ext_s < 0.0f) {
@@ -220,30 +216,6 @@ __device__ __forceinline__ void render_small_body(uint32_t wh, float cone_ext_s,
   }
 #endif
 
-  // ---- the rest of what the lane keeps about its primitive: the ray-independent terms of the exact primary
-  //      tests, its bound and its centre / plane normal (shadow rays, hit records) ----
-  float bx = 0.0f, by = 0.0f, bz = 0.0f, brad = 0.0f; // sphere centre + radius / triangle bound ball
-  float g0 = 0.0f, g1 = 0.0f, g2 = 0.0f;               // sphere centre / triangle plane normal
-  float e0 = 0.0f, e1 = 0.0f, e2 = 0.0f, e3 = 0.0f;    // sphere: o - c, |o - c|^2 - r^2;  triangle: e0 = k - n.o
-  float rr = 0.0f;                                     // sphere: r^2
-  int pobj = 0;
-  unsigned long long any_candidates = 0ull; // a wave whose tiles are all sky needs none of this (70 % of the default frame's)
-#pragma unroll
-  for (int j = 0; j < TPW; ++j) any_candidates |= pmask[j];
-  if (any_candidates == 0ull) {
-  } else if (own_s) {
-    e0 = S.prm[4][lane]; e1 = S.prm[5][lane]; e2 = S.prm[6][lane]; e3 = S.prm[7][lane];
-    pobj = __float_as_int(S.prm[8][lane]);
-    bx = sc.sph_cx[lane]; by = sc.sph_cy[lane]; bz = sc.sph_cz[lane]; brad = sc.sph_r[lane];
-    g0 = bx; g1 = by; g2 = bz;
-    rr = brad * brad;
-  } else if (own_t) {
-    const int k = lane - ns;
-    e0 = S.prm[12][lane];
-    pobj = __float_as_int(S.prm[13][lane]);
-    bx = sc.tri_bx[k]; by = sc.tri_by[k]; bz = sc.tri_bz[k]; brad = sc.tri_br[k];
-    g0 = sc.tri[k]; g1 = sc.tri[nt + k]; g2 = sc.tri[2 * nt + k];
-  }
   const unsigned long long smask_all = ns >= 64 ? ~0ull : ((1ull << ns) - 1ull);
   const bool valid_row = (lrow < A.local_rows) && (grow < A.H);
   unsigned int n_shadow = 0, n_hit = 0, n_occl = 0, n_valid = 0;
@@ -319,6 +291,27 @@ __device__ __forceinline__ void render_small_body(uint32_t wh, float cone_ext_s,
       }
     }
   } else {
+  // ---- the rest of what the lane keeps about its primitive: the ray-independent terms of the exact primary
+  //      tests, its bound and its centre / plane normal (shadow rays, hit records).  Fetched here, in tiles with
+  //      candidates only: 70 % of the default frame's tiles are sky and never need it ----
+  float bx = 0.0f, by = 0.0f, bz = 0.0f, brad = 0.0f; // sphere centre + radius / triangle bound ball
+  float g0 = 0.0f, g1 = 0.0f, g2 = 0.0f;               // sphere centre / triangle plane normal
+  float e0 = 0.0f, e1 = 0.0f, e2 = 0.0f, e3 = 0.0f;    // sphere: o - c, |o - c|^2 - r^2;  triangle: e0 = k - n.o
+  float rr = 0.0f;                                     // sphere: r^2
+  int pobj = 0;
+  if (own_s) {
+    e0 = S.prm[4][lane]; e1 = S.prm[5][lane]; e2 = S.prm[6][lane]; e3 = S.prm[7][lane];
+    pobj = __float_as_int(S.prm[8][lane]);
+    bx = sc.sph_cx[lane]; by = sc.sph_cy[lane]; bz = sc.sph_cz[lane]; brad = sc.sph_r[lane];
+    g0 = bx; g1 = by; g2 = bz;
+    rr = brad * brad;
+  } else if (own_t) {
+    const int k = lane - ns;
+    e0 = S.prm[12][lane];
+    pobj = __float_as_int(S.prm[13][lane]);
+    bx = sc.tri_bx[k]; by = sc.tri_by[k]; bz = sc.tri_bz[k]; brad = sc.tri_br[k];
+    g0 = sc.tri[k]; g1 = sc.tri[nt + k]; g2 = sc.tri[2 * nt + k];
+  }
   for (int sidx = 0; sidx < nsamp; ++sidx) {
     float offx, offy;
     sample_offset(sidx, offx, offy);
@@ -726,8 +719,9 @@ static void small_primary_functions(const RenderArgs &A, const SmallHost &hs, do
     const float cc = (e0 * e0 + (e1 * e1 + e2 * e2)) - rr;
     const float wx = cx - A.cam.ox, wy = cy - A.cam.oy, wz = cz - A.cam.oz;
     const double L2 = (double)wx * wx + (double)wy * wy + (double)wz * wz;
-    prm[0][i] = wx; prm[1][i] = wy; prm[2][i] = wz;
-    prm[3][i] = (float)((std::sqrt((double)rr + 2e-6 * L2) * 1.001 + 1e-6) * (1.0 + 1e-6)); // sphere_cull_radius, rounded up
+    // fields 9..12: the cone-test inputs (the bounce kernel's primary culling, mrt_bounce.hip); 0..3: the screen rectangle below
+    prm[9][i] = wx; prm[10][i] = wy; prm[11][i] = wz;
+    prm[12][i] = (float)((std::sqrt((double)rr + 2e-6 * L2) * 1.001 + 1e-6) * (1.0 + 1e-6)); // sphere_cull_radius, rounded up
     prm[4][i] = e0; prm[5][i] = e1; prm[6][i] = e2; prm[7][i] = cc;
     std::memcpy(&prm[8][i], &hs.sph_obj[i], 4);
   }
@@ -751,10 +745,10 @@ static void small_primary_functions(const RenderArgs &A, const SmallHost &hs, do
     const double plane_dist = nl > 0.0 ? std::fabs(dot(base, nrm)) / nl : 0.0; // every ray is at least this long
     for (int i = 0; i < ns; ++i) {
       float lo_u = -INFINITY, hi_u = INFINITY, lo_v = -INFINITY, hi_v = INFINITY;
-      const double w[3] = {prm[0][i], prm[1][i], prm[2][i]};
+      const double w[3] = {prm[9][i], prm[10][i], prm[11][i]};
       const double L = std::sqrt(dot(w, w));
-      if (plane_dist > 1e-30 && std::isfinite(L) && std::isfinite((double)prm[3][i])) {
-        const double R = ((double)prm[3][i] + L * (cam_delta / plane_dist) * 1.01) * (1.0 + 1e-6) + 1e-6 * L;
+      if (plane_dist > 1e-30 && std::isfinite(L) && std::isfinite((double)prm[12][i])) {
+        const double R = ((double)prm[12][i] + L * (cam_delta / plane_dist) * 1.01) * (1.0 + 1e-6) + 1e-6 * L;
         const double K = L * L - R * R;
         auto q = [&](const double *x, const double *y) { return dot(w, x) * dot(w, y) - K * dot(x, y); };
         const double a11 = q(h, h), a12 = q(h, vv), a22 = q(vv, vv), b1 = q(base, h), b2 = q(base, vv), c0 = q(base, base);
@@ -774,7 +768,7 @@ static void small_primary_functions(const RenderArgs &A, const SmallHost &hs, do
           }
         }
       }
-      prm[9][i] = lo_u; prm[10][i] = hi_u; prm[11][i] = lo_v; prm[12][i] = hi_v;
+      prm[0][i] = lo_u; prm[1][i] = hi_u; prm[2][i] = lo_v; prm[3][i] = hi_v;
     }
   }
   for (int j = 0; j < nt; ++j) {
