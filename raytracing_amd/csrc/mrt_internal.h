@@ -124,7 +124,7 @@ struct SmallArgs {
 };
 static_assert(sizeof(SmallArgs) <= 4096, "kernel arguments are limited to 4 KB");
 // fills S for tiles of 8P x 8 pixels (mrt_small.hip): S.A = args with cone_ext set, S.prm
-void small_prepare_args(const RenderArgs &args, const SmallHost &host, int P, SmallArgs &S);
+void small_prepare_args(const RenderArgs &args, const SmallHost &host, int P, SmallArgs &S, int lanes_across = 8);
 hipError_t launch_uv_table(float *utab, int nu, int W, float *vtab, int nv, int H, hipStream_t stream);
 // floats between the start of the u table and the start of the v table behind it: whole tiles of up to 32 pixels,
 // plus room for the one-tile-ahead fetches of a wave's last tile (up to 4 tiles of 32 pixels per wave)

@@ -121,7 +121,7 @@ struct SmallHot {
 };
 static_assert(sizeof(SmallHot) == 6 * 4, "the preloaded arguments are 5 dwords (+ 1 of alignment)");
 
-template <int P, bool MULTI, int TPW>
+template <int P, bool MULTI, int TPW, int LX>
 __device__ __forceinline__ void render_small_body(uint32_t wh, float cone_ext_s,
                                                   uint32_t meta, const float *utab_hot, const SmallArgs &S)
 {
@@ -129,8 +129,9 @@ __device__ __forceinline__ void render_small_body(uint32_t wh, float cone_ext_s,
   const DevScene &sc = A.sc;
   const DevCamera &cam = A.cam;
   const int lane = threadIdx.x; // one wave per workgroup
-  const int tx = lane & 7, ty = lane >> 3;
-  constexpr int TW = 8 * P;     // tile width in pixels
+  constexpr int LY = 64 / LX;   // a tile is LX lanes wide and LY rows high: 8 x 8 lanes or 16 x 4
+  const int tx = lane & (LX - 1), ty = lane / LX;
+  constexpr int TW = LX * P;    // tile width in pixels
   // ---- from the preloaded arguments only: no memory access has returned yet ----
   const int W = int(wh & 0xffffu) + 1, H = int(wh >> 16) + 1;
   constexpr int tpw = TPW;      // tiles per wave
@@ -144,7 +145,7 @@ __device__ __forceinline__ void render_small_body(uint32_t wh, float cone_ext_s,
   const int band_rows = int(meta >> 16);
   const int tile_y = int(blockIdx.y & (BANDS - 1)) * band_rows + int(blockIdx.y >> MRT_SMALL_BANDS_LOG2);
   const int tile_x0 = blockIdx.x * tpw;
-  const int lrow0 = tile_y * 8, lrow = lrow0 + ty;
+  const int lrow0 = tile_y * LY, lrow = lrow0 + ty;
   if (lrow0 >= H) return; // the grid is padded to BANDS * band_rows rows (and no rank has more rows than the frame)
 #ifdef MRT_TIMELINE
   const unsigned tl_idx = blockIdx.y * gridDim.x + blockIdx.x;
@@ -170,7 +171,7 @@ __device__ __forceinline__ void render_small_body(uint32_t wh, float cone_ext_s,
   int grow0 = lrow0;
   if (cone_ext_s < 0.0f) {
     if (lrow0 >= A.local_rows) return;
-    const int strip = lrow0 / A.strip_rows; // strips are multiples of 8 rows: a tile never straddles two
+    const int strip = lrow0 / A.strip_rows; // strips are multiples of 8 rows, LY divides 8: a tile never straddles two
     grow0 = (strip * A.nranks + A.rank) * A.strip_rows + (lrow0 - strip * A.strip_rows);
   }
   const int grow = grow0 + ty;
@@ -184,7 +185,7 @@ __device__ __forceinline__ void render_small_body(uint32_t wh, float cone_ext_s,
   //      ray of a padded tile is its centre ray plus an offset of norm <= cone_ext (launcher); which primitives
   //      can any ray of tile j hit? ----
   const float rw = fast_rcp(float(W)), rh = fast_rcp(float(H)); // bound arithmetic: approximate is fine
-  const float vm = (float(grow0) + 3.5f) * rh;
+  const float vm = (float(grow0) + 0.5f * float(LY - 1)) * rh;
   unsigned long long pmask[TPW];
 #pragma unroll
   for (int j = 0; j < TPW; ++j) {
@@ -694,11 +695,21 @@ __device__ __forceinline__ void render_small_body(uint32_t wh, float cone_ext_s,
 #ifndef MRT_SMALL_TPW_DEFAULT
 #define MRT_SMALL_TPW_DEFAULT 1
 #endif
+// Tile shape (experiment knob, default 8 x 8 lanes).  With two pixels per lane a tile of 16 x 4 lanes writes whole
+// 128-byte lines of the ID and t buffers (32 pixels x 4 B) where 8 x 8 lanes write 64-byte halves, and a store-only
+// kernel of that shape is faster (tools/ubench_launch.hip, non-temporal: 8.6 against 10.3 us for the 1080p frame) --
+// but the flat tiles have more outline for the same area, more of them hold a candidate, and the default frame takes
+// 17.05 us instead of 16.25 (make variant NAME=lx16 DEFS=-DMRT_SMALL_LX=16).
+#ifndef MRT_SMALL_LX
+#define MRT_SMALL_LX 8
+#endif
+constexpr int small_lanes_across(int P, bool multi) { return (P == 2 && !multi) ? MRT_SMALL_LX : 8; }
+
 template <int P, bool MULTI>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(P == 2 && !MULTI ? MRT_SMALL_WAVES : 1, 8)))
 void render_small_kernel(uint32_t wh, float cone_ext_s, uint32_t meta, const float *utab, SmallArgs S)
 {
-  render_small_body<P, MULTI, MRT_SMALL_TPW_DEFAULT>(wh, cone_ext_s, meta, utab, S);
+  render_small_body<P, MULTI, MRT_SMALL_TPW_DEFAULT, small_lanes_across(P, MULTI)>(wh, cone_ext_s, meta, utab, S);
 }
 
 // ---- primary-ray functions (host, double; per render) ---------------------------------------------------
@@ -804,13 +815,13 @@ static void small_primary_functions(const RenderArgs &A, const SmallHost &hs, do
   }
 }
 
-// Camera-dependent kernel arguments of a small scene for tiles of 8P x 8 pixels: cone extent and prm.
-void small_prepare_args(const RenderArgs &in, const SmallHost &hs, int P, SmallArgs &S)
+// Camera-dependent kernel arguments of a small scene for tiles of lx * P x 64 / lx pixels: cone extent and prm.
+void small_prepare_args(const RenderArgs &in, const SmallHost &hs, int P, SmallArgs &S, int lx)
 {
   S.A = in;
   RenderArgs &A = S.A;
-  // the padded tile (pixels -1..8P horizontally, -1..8 vertically) around its centre, in u / v units
-  const double hw = (4.0 * P + 0.5) / A.W, hh = 4.5 / A.H;
+  // the padded tile (pixels -1..lx P horizontally, -1..64 / lx vertically) around its centre, in u / v units
+  const double hw = (0.5 * lx * P + 0.5) / A.W, hh = (0.5 * (64 / lx) + 0.5) / A.H;
   double dmax = 0;
   {
     // largest offset of a ray of the padded tile from the tile's centre ray, in double, rounded up
@@ -841,13 +852,14 @@ template <int P>
 static hipError_t launch_small(const RenderArgs &in, const SmallHost &hs, hipStream_t stream)
 {
   SmallArgs S; // 3.5 KB of kernel arguments
-  small_prepare_args(in, hs, P, S);
+  const int lx = small_lanes_across(P, in.spp > 1), ly = 64 / lx;
+  small_prepare_args(in, hs, P, S, lx);
   RenderArgs &A = S.A;
   // vector stores need every lane's first pixel on a 4P-byte boundary in all three buffers
   const uintptr_t align = 4 * P - 1;
   A.wide = (A.W % P == 0) && ((uintptr_t)A.rgb & align) == 0 && ((uintptr_t)A.id & align) == 0 &&
            ((uintptr_t)A.t & align) == 0;
-  const int tiles_x = (A.W + 8 * P - 1) / (8 * P), tiles_y = (A.local_rows + 7) / 8;
+  const int tiles_x = (A.W + lx * P - 1) / (lx * P), tiles_y = (A.local_rows + ly - 1) / ly;
   if (tiles_x == 0 || tiles_y == 0) return hipSuccess;
   // the arguments the hardware preloads (SmallHot): camera in culling form, frame size, cone extent (its sign flags a
   // strip partition), the u table, tiles per wave and primitive counts

@@ -39,15 +39,16 @@ typedef float nfloat2 __attribute__((ext_vector_type(2)));
 typedef float nfloat4 __attribute__((ext_vector_type(4)));
 
 // a wave writes a tile of (8 * P * T) x 8 pixels: lane (tx, ty) owns P adjacent pixels in each of T tiles side by side
-template <int P, bool NT>
+// (LX lanes side by side, 64 / LX rows: LX = 8 is the render kernels' shape, LX = 16 writes 128-byte runs of id and t)
+template <int P, bool NT, int LX = 8>
 __global__ __launch_bounds__(256) void store_kernel(float *rgb, int *id, float *t, int W, int H, int T)
 {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int tx = lane & 7, ty = lane >> 3;
-  const int row = blockIdx.y * 8 + ty;
+  const int tx = lane & (LX - 1), ty = lane / LX;
+  const int row = blockIdx.y * (64 / LX) + ty;
   if (row >= H) return;
   for (int j = 0; j < T; ++j) {
-    const int col0 = ((blockIdx.x * (blockDim.x >> 6) + wave) * T + j) * 8 * P + tx * P;
+    const int col0 = ((blockIdx.x * (blockDim.x >> 6) + wave) * T + j) * LX * P + tx * P;
     if (col0 + P > W) return;
     const size_t pix = (size_t)row * W + col0;
     float v = (float)(row + col0) * 1e-6f;
@@ -122,5 +123,15 @@ int main()
   CASE(2, false, 1, 1) CASE(2, true, 1, 1) CASE(2, true, 2, 1) CASE(2, true, 4, 1)
   CASE(2, true, 1, 2) CASE(2, true, 1, 4)
   CASE(4, false, 1, 1) CASE(4, true, 1, 1) CASE(4, true, 4, 1) CASE(4, true, 1, 2) CASE(4, true, 1, 4)
+  printf("the same with tiles of 16 lanes x 4 rows (32 x 4 pixels at P=2: full 128-byte lines of id and t):\n");
+#define CASEW(P, NT, WPW, T) { dim3 g((W / (16 * P * T) + WPW - 1) / WPW, H / 4); \
+    float us = time_us([&] { hipLaunchKernelGGL((store_kernel<P, NT, 16>), g, dim3(64 * WPW), 0, 0, rgb, id, t, W, H, T); }); \
+    printf("  P=%d tiles/wave=%d waves/wg=%d nt=%d (%5d waves): %.2f us = %.0f GB/s\n", P, T, WPW, (int)NT, g.x * g.y * WPW, us, W * H * 20.0 / us * 1e-3); }
+  CASEW(1, false, 1, 1) CASEW(1, true, 1, 1) CASEW(2, false, 1, 1) CASEW(2, true, 1, 1) CASEW(2, true, 1, 2) CASEW(4, true, 1, 1)
+  printf("... and 32 lanes x 2 rows:\n");
+#define CASEV(P, NT) { dim3 g(W / (32 * P), H / 2); \
+    float us = time_us([&] { hipLaunchKernelGGL((store_kernel<P, NT, 32>), g, dim3(64), 0, 0, rgb, id, t, W, H, 1); }); \
+    printf("  P=%d nt=%d (%5d waves): %.2f us = %.0f GB/s\n", P, (int)NT, g.x * g.y, us, W * H * 20.0 / us * 1e-3); }
+  CASEV(1, false) CASEV(1, true) CASEV(2, false) CASEV(2, true)
   return 0;
 }
