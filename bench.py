@@ -324,8 +324,25 @@ def main():
         kern_ms = e0.elapsed_time(e1) / steps
     elapsed = float(el.item())
 
-    if args.dump_frame and world > 1:
+    # N > 1: is the frame that arrived on rank 0 the frame one GPU renders?  Outside the timed region: one more
+    # distributed frame, then rank 0 renders all of it alone and compares the three planes bit for bit.
+    frame_check = None
+    if world > 1:
         fr.step()
+        sync()
+        if rank == 0:
+            solo = multigpu.FrameRenderer(flat, cam12, W, H, device=local_rank, spp=spp, max_depth=max_depth)
+            solo.ctx.set_cull(0 if args.brute_force else 1)
+            solo.render_local()
+            torch.cuda.synchronize()
+            same = {k: bool(torch.equal(a.view(torch.int32), b.view(torch.int32)))
+                    for k, a, b in (("rgb", fr.rgb, solo.rgb), ("id", fr.ids, solo.ids), ("t", fr.tt, solo.tt))}
+            solo.close()
+            frame_check = {"what": f"the frame gathered from {world} ranks against rank 0 rendering all of it alone, "
+                                   "bit for bit", **{k + "_equal": v for k, v in same.items()}}
+            if not all(same.values()):
+                print(f"[bench] FRAME CHECK FAILED: {frame_check}", file=sys.stderr, flush=True)
+        sync()
     frame = fr.frame_host() if args.dump_frame else None
     if rank == 0 and frame is not None:
         import numpy as np
@@ -412,6 +429,8 @@ def main():
                                     "achieved": round(ach_tf, 4), "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
                                     "frac": round(ach_tf / VALU_PEAK_TFLOPS, 5),
                                     "algorithmic_flops_per_ray": flops_ray, "algorithmic_flops_per_launch": alg_flops}
+        if frame_check is not None:
+            out["frame_check"] = frame_check
         if world == 1:
             progress(f"GPU done ({ms_per_step:.4f} ms/step, kernel {kern_ms:.4f} ms); end-to-end frames")
             out["end_to_end"] = end_to_end(fr, cam12, W, H, spp, max_depth, rays_per_frame,

@@ -42,6 +42,8 @@ def test_bench_direct_invocation_with_two_and_four_ranks(tmp_path, config):
         assert js["config"]["primary_rays"] == one["config"]["primary_rays"]
         assert js["config"]["shadow_rays"] == one["config"]["shadow_rays"]
         assert "all three gathered" in js["config"]["outputs"]
+        chk = js["frame_check"]  # the bench's own 1-vs-N comparison, made on rank 0 after the timed region
+        assert chk["rgb_equal"] and chk["id_equal"] and chk["t_equal"], chk
         for k in ("rgb", "id", "t"):
             assert np.array_equal(fn[k], f1[k]), (n, k)
 
