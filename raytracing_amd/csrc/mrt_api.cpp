@@ -51,6 +51,7 @@ struct mrt_ctx {
   // launcher derives the camera-dependent culling functions from it for every render
   std::vector<float> small_tri16, small_sph;
   std::vector<int32_t> small_tri_obj, small_sph_obj;
+  mrt::SmallViewCache small_view; // last view of the small-scene launcher (reset by an upload)
 
   // per-pixel XORWOW streams of the diffuse bounce (mrt_rng.hip): jump matrices, and the xorshift words of
   // streams 0..rng_n-1 for seed rng_seed (5 streams of rng_n words), built on first need
@@ -236,9 +237,10 @@ static hipError_t ensure_rng_states(mrt_ctx *ctx, size_t npix)
   return hipSuccess;
 }
 
-static mrt::SmallHost small_host(const mrt_ctx *ctx)
+static mrt::SmallHost small_host(mrt_ctx *ctx)
 {
   mrt::SmallHost hs;
+  hs.view = &ctx->small_view;
   hs.ns = (int)ctx->small_sph_obj.size(); hs.nt = (int)ctx->small_tri_obj.size();
   hs.sph = ctx->small_sph.data(); hs.sph_obj = ctx->small_sph_obj.data();
   hs.tri16 = ctx->small_tri16.data(); hs.tri_obj = ctx->small_tri_obj.data();
@@ -541,6 +543,7 @@ int mrt_scene_upload(mrt_ctx *ctx, const mrt_scene_desc *s)
   ctx->have_scene = false;
   ctx->any_diffuse = false;
   ctx->small_sph.clear(); ctx->small_sph_obj.clear(); ctx->small_tri16.clear(); ctx->small_tri_obj.clear();
+  ctx->small_view = mrt::SmallViewCache();
   if (ctx->fail_next_upload) {
     ctx->fail_next_upload = false;
     if (ctx->scene_mem) { (void)hipFree(ctx->scene_mem); ctx->scene_mem = nullptr; ctx->scene_bytes = 0; }
@@ -571,6 +574,7 @@ int mrt_scene_upload(mrt_ctx *ctx, const mrt_scene_desc *s)
   for (size_t i = 0; i < no; ++i) ctx->any_diffuse |= (s->mat_kind[i] == MRT_MAT_DIFFUSE);
   ctx->small_sph.swap(new_sph); ctx->small_sph_obj.swap(new_sph_obj);
   ctx->small_tri16.swap(new_tri16); ctx->small_tri_obj.swap(new_tri_obj);
+  ctx->small_view = mrt::SmallViewCache();
   ctx->have_scene = true;
   return MRT_OK;
 }

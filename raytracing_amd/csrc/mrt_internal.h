@@ -101,7 +101,17 @@ hipError_t launch_render_cull(const RenderArgs &args, hipStream_t stream);
 
 // scenes of at most 64 primitives (mrt_small.hip); needs args.utab / args.vtab
 // host copy of a small scene in device order, from which the launcher derives the camera-dependent kernel arguments
+// What the small-scene launcher remembers about the last view it rendered (owned by the context, reset by an
+// upload): a caller that renders the same view again -- a benchmark loop, progressive accumulation, a paused viewer --
+// gets the launch order of its tile rows tuned to where that view's geometry is (mrt_small.hip, small_first_row).
+struct SmallViewCache {
+  struct Key { DevCamera cam; int W, H, local_rows, P, lx, partitioned; } key;
+  bool valid = false;
+  int seen = 0;   // renders of this view so far
+  int row0 = 0;   // first tile row to launch (0 until the view has been seen twice)
+};
 struct SmallHost {
+  SmallViewCache *view = nullptr; // optional
   int ns = 0, nt = 0;
   const float *sph = nullptr;       // [ns][4] centre xyz, radius
   const int32_t *sph_obj = nullptr; // [ns]

@@ -39,6 +39,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <type_traits>
+#include <vector>
 
 namespace mrt {
 
@@ -141,9 +142,17 @@ __device__ __forceinline__ void render_small_body(uint32_t wh, float cone_ext_s,
   // height and sky tiles (bound by the stores) run beside hit tiles (bound by instruction issue).  Measured on the
   // default frame: SLOWER, 17.8 -> 20.1 us with 2 or 8 bands (gpurun_out/exp_bands_*.txt), as is raising the priority
   // of hit waves (19.9 us): vector loads of a hit wave queue behind the stores of the sky waves that share its CU.
-  constexpr int BANDS = 1 << MRT_SMALL_BANDS_LOG2;
+  [[maybe_unused]] constexpr int BANDS = 1 << MRT_SMALL_BANDS_LOG2;
   const int band_rows = int(meta >> 16);
+#if MRT_SMALL_BANDS_LOG2 == 0
+  // Rows of tiles are launched starting at row `band_rows` (here: the launcher's row0, small_first_row) and wrap
+  // around: tiles with candidates live four times as long as sky tiles, so the band of the frame that holds the
+  // geometry should start first and the sky rows fill the machine while its last waves drain.
+  int tile_y = int(blockIdx.y) + band_rows;
+  tile_y = tile_y >= int(gridDim.y) ? tile_y - int(gridDim.y) : tile_y;
+#else
   const int tile_y = int(blockIdx.y & (BANDS - 1)) * band_rows + int(blockIdx.y >> MRT_SMALL_BANDS_LOG2);
+#endif
   const int tile_x0 = blockIdx.x * tpw;
   const int lrow0 = tile_y * LY, lrow = lrow0 + ty;
   if (lrow0 >= H) return; // the grid is padded to BANDS * band_rows rows (and no rank has more rows than the frame)
@@ -848,6 +857,68 @@ void small_prepare_args(const RenderArgs &in, const SmallHost &hs, int P, SmallA
 // live twice as long and the frame ends when the last of them does.
 static int small_tiles_per_wave() { return MRT_SMALL_TPW_DEFAULT; }
 
+// The tile row the launch starts with (the kernel wraps around).  Decided from the view itself, on the host, with the
+// kernel's own per-tile tests (S.prm) -- 16 200 tiles x 10 primitives for the default frame, a few hundred
+// microseconds -- so only for a view that is being rendered AGAIN (SmallViewCache): the first render of a view, and
+// every render of a camera that moves each frame, starts at row 0 and pays nothing.  Rule: skip the leading rows that
+// hold less than 2 % of the frame's candidate tiles, keep a margin of 1/20 of the rows before the geometry begins
+// (measured on the default frame, whose geometry begins in row 28 of 135: start rows 20-26 15.7-15.9 us, 0: 16.5,
+// 28: 16.4, 30: 16.9 -- the rows skipped run LAST, and a candidate tile that starts last is a tail).  Results do
+// not depend on the order.  MRT_SMALL_ROW0 = n pins the row (experiments), -1 = this rule.
+static int small_first_row(const SmallArgs &S, int ns, int nt, int P, int lx, int tiles_x, int tiles_y)
+{
+  const int TW = lx * P, LY = 64 / lx;
+  const float rw = 1.0f / float(S.A.W), rh = 1.0f / float(S.A.H);
+  std::vector<int> cand((size_t)tiles_y, 0);
+  long total = 0;
+  for (int y = 0; y < tiles_y; ++y) {
+    const float vm = (float(y * LY) + 0.5f * float(LY - 1)) * rh;
+    int c = 0;
+    for (int x = 0; x < tiles_x; ++x) {
+      const float um = (float(x * TW) + 0.5f * float(TW - 1)) * rw;
+      bool any = false;
+      for (int i = 0; i < ns && !any; ++i)
+        any = !(um < S.prm[0][i]) & !(um > S.prm[1][i]) & !(vm < S.prm[2][i]) & !(vm > S.prm[3][i]);
+      for (int j = ns; j < ns + nt && !any; ++j) {
+        bool cull = false;
+        for (int i = 0; i < 4; ++i)
+          cull |= std::fmaf(um, S.prm[3 * i + 1][j], std::fmaf(vm, S.prm[3 * i + 2][j], S.prm[3 * i][j])) < 0.0f;
+        any = !cull;
+      }
+      c += any ? 1 : 0;
+    }
+    cand[(size_t)y] = c;
+    total += c;
+  }
+  if (total == 0) return 0;
+  long cum = 0;
+  int first = 0;
+  for (; first < tiles_y; ++first) {
+    cum += cand[(size_t)first];
+    if (cum * 50 > total) break; // more than 2 % of the candidate tiles lie in rows 0..first
+  }
+  const int margin = tiles_y / 20 > 2 ? tiles_y / 20 : 2;
+  return first > margin ? first - margin : 0;
+}
+
+static int small_row0(const SmallArgs &S, const SmallHost &hs, int P, int lx, int tiles_x, int tiles_y, bool partitioned)
+{
+  static const int forced = [] { const char *e = getenv("MRT_SMALL_ROW0"); return e ? atoi(e) : -1; }();
+  if (forced >= 0) return forced % tiles_y;
+  SmallViewCache *vc = hs.view;
+  if (!vc || partitioned || tiles_y < 16) return 0; // strips of a partitioned frame are dealt over the ranks as they are
+  SmallViewCache::Key k;
+  std::memset(&k, 0, sizeof k);
+  k.cam = S.A.cam; k.W = S.A.W; k.H = S.A.H; k.local_rows = S.A.local_rows; k.P = P; k.lx = lx; k.partitioned = 0;
+  if (vc->valid && std::memcmp(&k, &vc->key, sizeof k) == 0) {
+    if (++vc->seen == 2) vc->row0 = small_first_row(S, hs.ns, hs.nt, P, lx, tiles_x, tiles_y);
+    if (vc->seen > (1 << 30)) vc->seen = 1 << 30;
+    return vc->row0 < tiles_y ? vc->row0 : 0;
+  }
+  vc->key = k; vc->valid = true; vc->seen = 1; vc->row0 = 0;
+  return 0;
+}
+
 template <int P>
 static hipError_t launch_small(const RenderArgs &in, const SmallHost &hs, hipStream_t stream)
 {
@@ -868,11 +939,13 @@ static hipError_t launch_small(const RenderArgs &in, const SmallHost &hs, hipStr
   const float cone_s = partitioned ? -A.cone_ext : A.cone_ext;
   const uint32_t wh = (uint32_t)(A.W - 1) | ((uint32_t)(A.H - 1) << 16);
   constexpr int BANDS = 1 << MRT_SMALL_BANDS_LOG2;
-  const int band_rows = (tiles_y + BANDS - 1) / BANDS; // < 65536: tiles_y <= 8192
+  int band_rows = (tiles_y + BANDS - 1) / BANDS; // < 65536: tiles_y <= 8192
+  const int grid_rows = band_rows * BANDS;
+  if (BANDS == 1) band_rows = small_row0(S, hs, P, lx, tiles_x, tiles_y, partitioned);
   const uint32_t meta = (uint32_t)A.sc.ns | ((uint32_t)A.sc.nt << 8) | ((uint32_t)band_rows << 16);
   // one wave per workgroup: waves share nothing, and single-wave workgroups fill freed wave slots sooner than
   // groups of four (measured 19.4 against 19.9 us on the default frame)
-  const dim3 grid((tiles_x + tpw - 1) / tpw, band_rows * BANDS);
+  const dim3 grid((tiles_x + tpw - 1) / tpw, grid_rows);
   if (A.spp > 1)
     hipLaunchKernelGGL((render_small_kernel<P, true>), grid, dim3(64), 0, stream, wh, cone_s, meta, A.utab, S);
   else
