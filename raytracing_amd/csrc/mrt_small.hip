@@ -98,6 +98,9 @@ template <class T> __device__ __forceinline__ void frame_store(const T &x, T *p)
 {
   if (MRT_SMALL_NT) __builtin_nontemporal_store(x, p); else *p = x;
 }
+#ifdef MRT_SMALL_ORDER_TABLE
+__device__ unsigned short g_order[8192];
+#endif
 #ifdef MRT_TIMELINE
 // Diagnostic build only (tools/timeline.py): per wave, shader-clock stamps at entry, after the culling prologue,
 // before the stores and at exit, the 100 MHz real-time clock at entry, and where the wave ran.
@@ -144,7 +147,11 @@ __device__ __forceinline__ void render_small_body(uint32_t wh, float cone_ext_s,
   // of hit waves (19.9 us): vector loads of a hit wave queue behind the stores of the sky waves that share its CU.
   [[maybe_unused]] constexpr int BANDS = 1 << MRT_SMALL_BANDS_LOG2;
   const int band_rows = int(meta >> 16);
-#if MRT_SMALL_BANDS_LOG2 == 0
+#ifdef MRT_SMALL_ORDER_TABLE
+  // experiment builds only (tools/exp_order.py): the row of tiles comes from a table set through mrt_diag_set_order
+  int tile_y = g_order[blockIdx.y];
+  (void)band_rows;
+#elif MRT_SMALL_BANDS_LOG2 == 0
   // Rows of tiles are launched starting at row `band_rows` (here: the launcher's row0, small_first_row) and wrap
   // around: tiles with candidates live four times as long as sky tiles, so the band of the frame that holds the
   // geometry should start first and the sky rows fill the machine while its last waves drain.
@@ -966,6 +973,13 @@ static int small_pixels_per_lane(int spp)
   return forced ? forced : (spp > 1 ? 1 : 2);
 }
 
+#ifdef MRT_SMALL_ORDER_TABLE
+extern "C" int mrt_diag_set_order(const unsigned short *rows, size_t n)
+{
+  if (n > 8192) return -1;
+  return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_order), rows, n * sizeof(unsigned short), 0, hipMemcpyHostToDevice);
+}
+#endif
 #ifdef MRT_TIMELINE
 extern "C" int mrt_diag_timeline(unsigned long long *host_out, size_t words)
 {
