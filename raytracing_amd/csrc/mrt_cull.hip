@@ -66,11 +66,23 @@ template <> struct CVec<4> { typedef float f __attribute__((ext_vector_type(4)))
 // dealing leaves would repeat that set-up in every member.  The reference adds the lights' contributions to a pixel
 // in light order (core/light.cuh:171-173; fp32 addition does not associate), so a member does not add up its own
 // lights: it leaves each light's contribution in LDS, and member 0 folds them in order, 32 lights at a time.
+#ifndef MRT_REFINE_RIGOROUS
+#define MRT_REFINE_RIGOROUS 1
+#endif
+#ifndef MRT_REFINE_U
+#define MRT_REFINE_U 3e-7f
+#endif
+#ifndef MRT_REFINE_EPS
+#define MRT_REFINE_EPS 1e-4f // relative margin of the leaf refinement's edge functions (the exact test rounds at 6e-8)
+#endif
 #ifndef MRT_CULL_TEAM_WAVES
 #define MRT_CULL_TEAM_WAVES 1 // 7 fits the team kernels into 72 registers only by spilling to scratch (C4 3 % faster, 0.3 GB of extra writes per frame): left alone
 #endif
+#ifndef MRT_CULL_LSPLIT_WAVES
+#define MRT_CULL_LSPLIT_WAVES 6 // the lights-dealing team kernel sits at 80 / 81 registers: keep it on the 6-wave side
+#endif
 template <bool HIER, int P, bool MULTI, int NW, bool LSPLIT = false>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NW > 1 && !MULTI ? MRT_CULL_TEAM_WAVES : 1, 8)))
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NW > 1 && !MULTI ? (LSPLIT ? MRT_CULL_LSPLIT_WAVES : MRT_CULL_TEAM_WAVES) : 1, 8)))
 void render_cull_kernel(RenderArgs A)
 {
   const DevScene &sc = A.sc;
@@ -265,6 +277,7 @@ void render_cull_kernel(RenderArgs A)
       const int i = base + lane;
       bool pass = false;
       if (i < nt) pass = tri_ball_in_reach(sc.tri_bx[i], sc.tri_by[i], sc.tri_bz[i], sc.tri_br[i]);
+      bool moved = false;
       if (HIER && __popcll(__ballot(pass)) >= TRI_REFINE_MIN && pass) {
         // Many candidates in one leaf (the usual leaf has one to three): worth a closer look at each, lane-parallel,
         // before the wave spends a division and up to three edge tests on every one of them for all its pixels.
@@ -303,6 +316,8 @@ void render_cull_kernel(RenderArgs A)
           if (pass) {
             const float sgn = lo > 0.0f ? 1.0f : -1.0f;
             const float dl = dlen_max * 1.01f; // the padded tile's rays are a little longer than the pixels'
+            [[maybe_unused]] const float N1 = fabsf(kp) + pn1 * o1;
+            [[maybe_unused]] const float inv_lo = fast_rcp(fminf(fabsf(lo), fabsf(hi))) * 1.01f; // 1 / min |n.u| over the cone
 #pragma unroll
             for (int e = 0; e < 3; ++e) {
               const float mx = sc.tri[(4 + 4 * e) * snt + i], my = sc.tri[(5 + 4 * e) * snt + i],
@@ -312,10 +327,26 @@ void render_cull_kernel(RenderArgs A)
               const float top = sgn * dot3(wx, wy, wz, dcx, dcy, dcz) + fabsf(dot3(wx, wy, wz, ehx, ehy, ehz)) +
                                 fabsf(dot3(wx, wy, wz, evx, evy, evz));
               const float m1 = norm1(mx, my, mz);
-              // 1e-4 of the magnitudes behind w.d and behind the exact test's e_i |n.d|; the rounding of the rays
-              // themselves (coarse far from the world origin: camera_rounding) through |w|; the exact test's -1e-6
-              const float err = 1e-4f * ((m1 * o1 + fabsf(ce)) * pn1 + fabsf(num) * m1) * (2.0f * dl) +
+              // How far can the exact test's fp32 e_i |n.d| be from w_i.d as computed here?  First-order rounding
+              // analysis of both (u = 2^-24 per operation, 1-norms for the sums):
+              //   num = k - n.o        off by 4u N1,  N1 = |k| + |n|1 |o|1
+              //   t = num / (n.d)      relative 4u N1 / |num| + 3u |n|1 |d| / |n.d| + u  -- the middle term is what a
+              //                        grazing ray amplifies: |n.d| >= lo_abs |d| over the cone bounds it
+              //   p = o + t d, e = m.p - c   move by |m.d| |dt| + 5u (|m|1 |o|1 + |m.d| |t|) + u |c|
+              // times |n.d| <= big |d|, plus this block's own a, w and w.d (4u each of their magnitudes):
+              //   u dl [ m1 (8 N1 + 7 |num| + 3.5 |n|1 |num| / lo_abs) + (4 |n|1 + 5 big)(m1 |o|1 + |c|) + 4 |w|1 ]
+              // taken five times over (REFINE_U = 3e-7); then the rounding of the rays themselves (coarse far from the
+              // world origin: camera_rounding) through |w|, and the exact test's own -1e-6.  (Until round 2 this was a
+              // flat 1e-4 of the magnitudes: three times as many candidates on the 1M-triangle terrain.)
+#if MRT_REFINE_RIGOROUS
+              const float w1 = norm1(wx, wy, wz);
+              const float err = MRT_REFINE_U * dl * (m1 * (8.0f * N1 + fabsf(num) * (7.0f + 3.5f * pn1 * inv_lo)) +
+                                                     (4.0f * pn1 + 5.0f * big) * (m1 * o1 + fabsf(ce)) + 4.0f * w1) +
+                                w1 * cam_round + 1e-6f * big * dl;
+#else
+              const float err = MRT_REFINE_EPS * ((m1 * o1 + fabsf(ce)) * pn1 + fabsf(num) * m1) * (2.0f * dl) +
                                 norm1(wx, wy, wz) * cam_round + 1e-6f * big * dl;
+#endif
               if (top + err < 0.0f) pass = false; // NaN compares false: never culls
             }
           }
@@ -323,7 +354,6 @@ void render_cull_kernel(RenderArgs A)
       }
       unsigned long long mask = __ballot(pass);
       n_clusters++; n_exact += __popcll(mask);
-      bool moved = false;
       while (mask) {
         const int j = __builtin_ctzll(mask);
         mask &= mask - 1;
