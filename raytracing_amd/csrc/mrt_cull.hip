@@ -66,6 +66,9 @@ template <> struct CVec<4> { typedef float f __attribute__((ext_vector_type(4)))
 // dealing leaves would repeat that set-up in every member.  The reference adds the lights' contributions to a pixel
 // in light order (core/light.cuh:171-173; fp32 addition does not associate), so a member does not add up its own
 // lights: it leaves each light's contribution in LDS, and member 0 folds them in order, 32 lights at a time.
+#ifndef MRT_REFINE_MD
+#define MRT_REFINE_MD 1
+#endif
 #ifndef MRT_REFINE_RIGOROUS
 #define MRT_REFINE_RIGOROUS 1
 #endif
@@ -340,9 +343,19 @@ void render_cull_kernel(RenderArgs A)
               // flat 1e-4 of the magnitudes: three times as many candidates on the 1M-triangle terrain.)
 #if MRT_REFINE_RIGOROUS
               const float w1 = norm1(wx, wy, wz);
+#if MRT_REFINE_MD
+              // the amplified term moves p ALONG THE RAY, so it reaches e_i through |m.d|, not |m| |d|: bound that over
+              // the padded tile (centre value + extents) instead of by norms
+              const float md = (fabsf(dot3(mx, my, mz, dcx, dcy, dcz)) + fabsf(dot3(mx, my, mz, ehx, ehy, ehz)) +
+                                fabsf(dot3(mx, my, mz, evx, evy, evz))) * 1.001f;
+              const float err = MRT_REFINE_U * (dl * m1 * (8.0f * N1 + 7.0f * fabsf(num)) + md * 3.5f * pn1 * fabsf(num) * inv_lo +
+                                                dl * ((4.0f * pn1 + 5.0f * big) * (m1 * o1 + fabsf(ce)) + 4.0f * w1)) +
+                                w1 * cam_round + 1e-6f * big * dl;
+#else
               const float err = MRT_REFINE_U * dl * (m1 * (8.0f * N1 + fabsf(num) * (7.0f + 3.5f * pn1 * inv_lo)) +
                                                      (4.0f * pn1 + 5.0f * big) * (m1 * o1 + fabsf(ce)) + 4.0f * w1) +
                                 w1 * cam_round + 1e-6f * big * dl;
+#endif
 #else
               const float err = MRT_REFINE_EPS * ((m1 * o1 + fabsf(ce)) * pn1 + fabsf(num) * m1) * (2.0f * dl) +
                                 norm1(wx, wy, wz) * cam_round + 1e-6f * big * dl;
