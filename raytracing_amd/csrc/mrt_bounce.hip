@@ -105,7 +105,18 @@ __device__ __forceinline__ const RenderArgs &args_of(const SmallArgs &s) { retur
 __device__ __forceinline__ float prm_of(const RenderArgs &, int, int) { return 0.0f; }
 __device__ __forceinline__ float prm_of(const SmallArgs &s, int f, int lane) { return s.prm[f][lane]; }
 
-template <bool MULTI, bool SMALL, class Args>
+#ifdef MRT_TIMELINE
+// Diagnostic build only (make variant DEFS=-DMRT_TIMELINE; tools/timeline_cull.py REF): per tile the 100 MHz real-time
+// clock at entry and exit of its wave, the shader clock it lived, chain steps | loop iterations.
+enum { TLB_WORDS = 4, TLB_MAX_WAVES = 1 << 18 };
+__device__ unsigned long long g_timeline_bounce[TLB_WORDS * TLB_MAX_WAVES];
+extern "C" int mrt_diag_timeline_bounce(unsigned long long *host_out, size_t words)
+{
+  return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_timeline_bounce), words * sizeof(unsigned long long), 0, hipMemcpyDeviceToHost);
+}
+#endif
+
+template <bool MULTI, bool SMALL, int WPB, class Args>
 __device__ __forceinline__ void render_bounce_body(const Args &S)
 {
   const RenderArgs &A = args_of(S);
@@ -117,10 +128,17 @@ __device__ __forceinline__ void render_bounce_body(const Args &S)
   const int ns = sc.ns, nt = sc.nt;
 
   const int tiles_x = (A.W + 7) >> 3, tiles_y = (A.local_rows + 7) >> 3;
-  const int widx = blockIdx.x * 4 + wave;
+  const int widx = blockIdx.x * WPB + wave; // WPB waves per workgroup, each with a tile of its own
   if (widx >= tiles_x * tiles_y) return; // waves are independent: no barrier below
   const int tile = A.tile_order ? int(A.tile_order[widx]) : widx; // heaviest tiles first (launcher), or row by row
+  // (The frame ends when its slowest wave does, and with many samples per pixel that is ONE wave's serial work: 121
+  // samples x 9 levels of a pixel between two mirrors are ~1050 loop iterations of ~12 000 cycles each, whether the wave
+  // shares its SIMD or not -- tools/timeline_cull.py REF: every wave has started after 2.5 ms, the last ends at 5.5.
+  // Raising the priority of the heaviest tiles' waves changes nothing, nor does a build without register spills.)
   const int tile_y = tile / tiles_x, tile_x = tile - tile_y * tiles_x;
+#ifdef MRT_TIMELINE
+  const unsigned long long tl_rt0 = __builtin_amdgcn_s_memrealtime(), tl_c0 = __builtin_amdgcn_s_memtime();
+#endif
   const int col = tile_x * 8 + tx;
   const int lrow = tile_y * 8 + ty;
   const int lrow0 = tile_y * 8;
@@ -137,7 +155,7 @@ __device__ __forceinline__ void render_bounce_body(const Args &S)
   // sample offsets of the 11 x 11 mesh (pipeline/multisample_mesh.cuh:23-30): four IEEE divisions per sample if
   // computed on the spot; instead every wave tabulates its 22 values once (LDS, one slice per wave) and lanes
   // look theirs up -- lanes sit at different samples, and a table read does not care which lanes are active
-  __shared__ float offtab[4][32];
+  __shared__ float offtab[WPB][32];
   if (MULTI) {
     if (lane < 11) offtab[wave][lane] = (-1.0f + 2.0f * float(lane + 1) / DIVW) / float(A.W);
     else if (lane >= 16 && lane < 27) offtab[wave][lane] = (-1.0f + 2.0f * float(lane - 16 + 1) / DIVH) / float(A.H);
@@ -230,7 +248,7 @@ __device__ __forceinline__ void render_bounce_body(const Args &S)
   // r, object; triangles the 16 floats + object), written once by the owning lanes and read back with one address
   // for the whole wave (broadcast).  The loops below then wait ~100 cycles of LDS latency per primitive instead of
   // a scalar-cache round trip, and nothing competes for scalar registers.  Larger scenes: scalar loads.
-  __shared__ float scene_lds[SMALL ? 4 : 1][SMALL ? 64 * 20 : 1];
+  __shared__ float scene_lds[SMALL ? WPB : 1][SMALL ? 64 * 20 : 1];
   if (SMALL && tile_has_candidates) {
     float *rec = &scene_lds[wave][lane * 20];
     if (own_s) {
@@ -764,6 +782,13 @@ __device__ __forceinline__ void render_bounce_body(const Args &S)
     if (A.t) A.t[pix] = out_t;
   }
 
+#ifdef MRT_TIMELINE
+  if (lane == 0 && tile < TLB_MAX_WAVES) {
+    unsigned long long *tlp = g_timeline_bounce + (size_t)TLB_WORDS * tile;
+    tlp[0] = tl_rt0; tlp[1] = __builtin_amdgcn_s_memrealtime(); tlp[2] = __builtin_amdgcn_s_memtime() - tl_c0;
+    tlp[3] = (unsigned long long)n_steps | ((unsigned long long)n_iter << 32);
+  }
+#endif
   if (A.stats) {
     // counters are spread over stats_slots copies: same-address atomics cost ~12 ns each, one after the other
     unsigned long long *st = A.stats + 8u * (blockIdx.x & (unsigned)(A.stats_slots - 1));
@@ -930,12 +955,21 @@ __global__ __launch_bounds__(256) void bounce_order_kernel(const uint32_t *__res
 // three waves per SIMD (at most 168 registers): left alone the compiler takes 172 and loses a wave
 template <bool MULTI>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8)))
-void render_bounce_kernel(RenderArgs A) { render_bounce_body<MULTI, false>(A); }
+void render_bounce_kernel(RenderArgs A) { render_bounce_body<MULTI, false, 4>(A); }
 // four waves per SIMD (128 registers, ~30 spilled: 5.85 ms on the reference's frame against 6.05 with the 157 the
 // compiler takes by itself; five waves spill far too much: 10 ms)
+// One wave per workgroup: the waves share nothing, and a tile of the reference's frame lives between 12 us (sky) and
+// more than a millisecond -- a workgroup of four keeps its four wave slots until the slowest is done (measured on the
+// reference's frame: 1.6 of 4 slots per SIMD in use on average with four waves per workgroup).
+#ifndef MRT_BOUNCE_SMALL_WAVES
+#define MRT_BOUNCE_SMALL_WAVES 4
+#endif
+#ifndef MRT_BOUNCE_WPB
+#define MRT_BOUNCE_WPB 1
+#endif
 template <bool MULTI>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8)))
-void render_bounce_small_kernel(SmallArgs S) { render_bounce_body<MULTI, true>(S); }
+__global__ __launch_bounds__(64 * MRT_BOUNCE_WPB) __attribute__((amdgpu_waves_per_eu(MRT_BOUNCE_SMALL_WAVES, 8)))
+void render_bounce_small_kernel(SmallArgs S) { render_bounce_body<MULTI, true, MRT_BOUNCE_WPB>(S); }
 
 hipError_t launch_render_bounce(const RenderArgs &in, const SmallHost *hs, uint32_t *scratch, hipStream_t stream)
 {
@@ -966,8 +1000,9 @@ hipError_t launch_render_bounce(const RenderArgs &in, const SmallHost *hs, uint3
       if ((e = hipGetLastError()) != hipSuccess) return e;
       S.A.tile_order = order;
     }
-    if (in.spp > 1) hipLaunchKernelGGL(render_bounce_small_kernel<true>, grid, block, 0, stream, S);
-    else hipLaunchKernelGGL(render_bounce_small_kernel<false>, grid, block, 0, stream, S);
+    const dim3 sgrid((ntiles + MRT_BOUNCE_WPB - 1) / MRT_BOUNCE_WPB), sblock(64 * MRT_BOUNCE_WPB);
+    if (in.spp > 1) hipLaunchKernelGGL(render_bounce_small_kernel<true>, sgrid, sblock, 0, stream, S);
+    else hipLaunchKernelGGL(render_bounce_small_kernel<false>, sgrid, sblock, 0, stream, S);
     return hipGetLastError();
   }
   RenderArgs A = in;

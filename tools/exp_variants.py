@@ -10,12 +10,16 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
         flat, cam = scenes.default_scene(); W, H = 1920, 1080
         cam12 = capi.viewport(cam["look_from"], cam["look_at"], cam["up"], cam["vfov"], W / H)
     else:
-        spec = {"C3": lambda: scenes.sphere_field(10000), "C5": scenes.light_stress,
+        if cfg == "REF":
+            flat, cam = scenes.default_scene(); W, H = 2048, 1024
+            cam12 = capi.viewport(cam["look_from"], cam["look_at"], cam["up"], cam["vfov"], W / H)
+        spec = {"REF": lambda: None, "C3": lambda: scenes.sphere_field(10000), "C5": scenes.light_stress,
                 "C4s": lambda: scenes.triangle_terrain(100, 50), "C4": lambda: scenes.triangle_terrain(1000, 500),
                 "C4m": lambda: scenes.triangle_terrain(300, 150)}[cfg]()
-        W, H = (3840, 2160) if cfg in ("C3", "C4", "C4m") else (1920, 1080)
-        flat = spec.flatten(); cam12 = spec.cam12(W / H)
-    fr = multigpu.FrameRenderer(flat, cam12, W, H)
+        if cfg != "REF":
+            W, H = (3840, 2160) if cfg in ("C3", "C4", "C4m") else (1920, 1080)
+            flat = spec.flatten(); cam12 = spec.cam12(W / H)
+    fr = multigpu.FrameRenderer(flat, cam12, W, H, **({"spp": 121, "max_depth": 8} if cfg == "REF" else {}))
     n = 400 if cfg == "C2" else 5
     best = None
     for rep in range(3):   # HIP events around n back-to-back launches; best of three

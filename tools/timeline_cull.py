@@ -21,9 +21,14 @@ def main():
     from raytracing_amd import capi, multigpu, scenes
 
     cfg = sys.argv[1] if len(sys.argv) > 1 else "C5"
-    spec, (W, H) = {"C3": (scenes.sphere_field(10000), (3840, 2160)), "C4": (scenes.triangle_terrain(1000, 500), (3840, 2160)),
+    kw = {}
+    if cfg == "REF":  # the bounce kernel on the reference's own frame (stamps: mrt_bounce.hip)
+        flat, cam = scenes.default_scene(); W, H = 2048, 1024
+        cam12 = capi.viewport(cam["look_from"], cam["look_at"], cam["up"], cam["vfov"], W / H)
+        kw = {"spp": 121, "max_depth": 8}
+    spec, (W, H) = (None, (W, H)) if cfg == "REF" else {"C3": (scenes.sphere_field(10000), (3840, 2160)), "C4": (scenes.triangle_terrain(1000, 500), (3840, 2160)),
                     "C5": (scenes.light_stress(), (1920, 1080))}[cfg]
-    fr = multigpu.FrameRenderer(spec.flatten(), spec.cam12(W / H), W, H)
+    fr = multigpu.FrameRenderer(flat, cam12, W, H, **kw) if cfg == "REF" else multigpu.FrameRenderer(spec.flatten(), spec.cam12(W / H), W, H)
     for _ in range(3):
         fr.render_local()
     torch.cuda.synchronize()
@@ -31,8 +36,9 @@ def main():
     tx, ty = (W + 7) // 8, (H + 7) // 8
     nw = tx * ty
     buf = np.zeros(nw * 4, dtype=np.uint64)
-    L.mrt_diag_timeline_cull.argtypes = [C.c_void_p, C.c_size_t]
-    assert L.mrt_diag_timeline_cull(buf.ctypes.data, buf.size) == 0
+    diag = L.mrt_diag_timeline_bounce if cfg == "REF" else L.mrt_diag_timeline_cull
+    diag.argtypes = [C.c_void_p, C.c_size_t]
+    assert diag(buf.ctypes.data, buf.size) == 0
     t = buf.reshape(nw, 4).astype(np.int64)
     rt0 = t[:, 0].min()
     start, end = (t[:, 0] - rt0) * 10.0 / 1e3, (t[:, 1] - rt0) * 10.0 / 1e3   # us
