@@ -460,6 +460,57 @@ def _random_scene(seed, lo=1, hi=90):
     return scenes.SceneSpec(f"random{seed}", sp, sphere_obj, tv, tri_obj, kind, rgb, lights, cam)
 
 
+def _grazing_terrain(seed, shift=0.0, scale=1.0):
+    """A height field seen from a low, grazing camera (tools/stress_terrain.py draws the same family): thousands of
+    sub-pixel triangles per tile along the horizon, where t = num / (n.d) is least accurate."""
+    import sys
+    tools = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools")
+    if tools not in sys.path:
+        sys.path.insert(0, tools)
+    from stress_common import moved
+    rng = np.random.default_rng(seed)
+    nx, nz = int(rng.integers(40, 260)), int(rng.integers(40, 200))
+    amp = float(10.0 ** rng.uniform(-2, 0.5))
+    tv = scenes.terrain_triangles(nx, nz, amp=amp)
+    n = tv.shape[0]
+    kind, rgb = scenes._cycle_materials(n)
+    height = float(-2.0 + amp + 10.0 ** rng.uniform(-2, 1.2))
+    cam = {"look_from": (float(rng.uniform(-30, 30)), height, float(rng.uniform(-20, 5))),
+           "look_at": (float(rng.uniform(-40, 40)), float(-2.0 + rng.uniform(-1, 3)), float(rng.uniform(-150, -60))),
+           "up": (0.02, 1.0, 0.01), "vfov": float(rng.uniform(8, 70))}
+    lights = [(capi.LIGHT_DIRECTIONAL, tuple(rng.normal(size=3) * (1, 0.3, 1) - (0, 0.6, 0)), (3.0, 2.5, 2.0)),
+              (capi.LIGHT_POINT, (float(rng.uniform(-30, 30)), float(rng.uniform(0, 20)), float(rng.uniform(-120, -20))),
+               (0.6, 0.8, 1.0))]
+    spec = scenes.SceneSpec(f"terrain{seed}", np.zeros((0, 4), np.float32), [], tv, np.arange(n), kind, rgb, lights, cam)
+    W, H = int(rng.integers(20, 90)) * 8, int(rng.integers(10, 50)) * 8 + int(rng.integers(0, 8))
+    return moved(spec, shift, scale), W, H
+
+
+@pytest.mark.parametrize("seed,shift,scale", [(101, 0.0, 1.0), (102, 0.0, 1.0), (103, 0.0, 1.0), (104, 0.0, 1.0),
+                                               (229, 3e4, 1.0), (230, 3e4, 1.0), (310, 1e3, 30.0), (311, 1e3, 30.0),
+                                               (1301, 1e5, 0.1), (1302, 1e5, 0.1)])
+def test_grazing_terrains_against_brute_force(gpu_ctx, seed, shift, scale):
+    """The leaf refinement culls with a first-order rounding bound of the exact triangle test (mrt_cull.hip,
+    DESIGN 5.2); grazing views of a terrain are where that bound is tightest against what the test really does.
+    Tile-culling kernel, with and without teams, against the brute-force kernel: id, t and rgb bit for bit."""
+    spec, W, H = _grazing_terrain(seed, shift, scale)
+    cam12 = spec.cam12(W / H)
+    gpu_ctx.upload(spec.flatten())
+    gpu_ctx.set_cull(0)
+    ref = gpu_ctx.render(cam12, W, H)
+    gpu_ctx.set_cull(2)
+    try:
+        for team in (1, 4):
+            gpu_ctx.set_cull_team(team)
+            g = gpu_ctx.render(cam12, W, H)
+            for k in ("id", "t", "rgb"):
+                assert np.array_equal(g[k].view(np.int32), ref[k].view(np.int32)), (seed, team, k)
+            assert_stats_parity(g["stats"], ref["stats"])
+    finally:
+        gpu_ctx.set_cull_team(0)
+        gpu_ctx.set_cull(1)
+
+
 @pytest.mark.parametrize("seed", [3, 11, 29, 57])
 def test_small_scenes_rendered_again_and_again(gpu_ctx, seed):
     """The small-scene launcher tunes the launch order of the tile rows to a view it has seen before (from the
