@@ -72,6 +72,37 @@ __global__ __launch_bounds__(256) void store_kernel(float *rgb, int *id, float *
   }
 }
 
+
+// the render kernels' tile (8 x 8 lanes, 2 pixels per lane) written with each cache-policy combination of
+// global_store_dwordx2 (vector stores; MODE: 0 plain, 1 nt, 2 sc0, 3 sc1, 4 sc0 sc1, 5 sc0 nt, 6 sc1 nt, 7 sc0 sc1 nt).
+// Measured: plain 9.5 us, sc0 9.5, nt 19.7, sc1 18.6, sc0 sc1 18.6, sc0 nt 20.6, sc1 nt 35.0, sc0 sc1 nt 35.0 -- no
+// combination beats the two the render kernel has tried (plain, nt).
+template <int MODE>
+__device__ __forceinline__ void st2(void *p, nfloat2 v)
+{
+  if constexpr (MODE == 0) asm volatile("global_store_dwordx2 %0, %1, off" ::"v"(p), "v"(v) : "memory");
+  if constexpr (MODE == 1) asm volatile("global_store_dwordx2 %0, %1, off nt" ::"v"(p), "v"(v) : "memory");
+  if constexpr (MODE == 2) asm volatile("global_store_dwordx2 %0, %1, off sc0" ::"v"(p), "v"(v) : "memory");
+  if constexpr (MODE == 3) asm volatile("global_store_dwordx2 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
+  if constexpr (MODE == 4) asm volatile("global_store_dwordx2 %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory");
+  if constexpr (MODE == 5) asm volatile("global_store_dwordx2 %0, %1, off sc0 nt" ::"v"(p), "v"(v) : "memory");
+  if constexpr (MODE == 6) asm volatile("global_store_dwordx2 %0, %1, off sc1 nt" ::"v"(p), "v"(v) : "memory");
+  if constexpr (MODE == 7) asm volatile("global_store_dwordx2 %0, %1, off sc0 sc1 nt" ::"v"(p), "v"(v) : "memory");
+}
+template <int MODE>
+__global__ __launch_bounds__(64) void store_mode_kernel(float *rgb, int *id, float *t, int W, int H)
+{
+  const int lane = threadIdx.x & 63;
+  const int tx = lane & 7, ty = lane >> 3;
+  const int row = blockIdx.y * 8 + ty, col0 = blockIdx.x * 16 + tx * 2;
+  if (row >= H || col0 + 2 > W) return;
+  const size_t pix = (size_t)row * W + col0;
+  const float v = (float)(row + col0) * 1e-6f;
+  nfloat2 a = {v, v + 1.f}, b = {v + 2.f, v}, c = {v + 1.f, v + 2.f};
+  st2<MODE>(rgb + 3 * pix, a); st2<MODE>(rgb + 3 * pix + 2, b); st2<MODE>(rgb + 3 * pix + 4, c);
+  st2<MODE>(id + pix, a); st2<MODE>(t + pix, b);
+}
+
 template <class F> static float time_us(F launch, int n = 400)
 {
   hipEvent_t e0, e1;
@@ -123,6 +154,13 @@ int main()
   CASE(2, false, 1, 1) CASE(2, true, 1, 1) CASE(2, true, 2, 1) CASE(2, true, 4, 1)
   CASE(2, true, 1, 2) CASE(2, true, 1, 4)
   CASE(4, false, 1, 1) CASE(4, true, 1, 1) CASE(4, true, 4, 1) CASE(4, true, 1, 2) CASE(4, true, 1, 4)
+  printf("16 x 8-pixel tiles, dwordx2 stores, by cache policy:\n");
+  {
+    const char *names[8] = {"plain", "nt", "sc0", "sc1", "sc0 sc1", "sc0 nt", "sc1 nt", "sc0 sc1 nt"};
+    dim3 g(W / 16, 135);
+#define MODE_CASE(M) printf("  %-12s %.2f us\n", names[M], time_us([&] { hipLaunchKernelGGL((store_mode_kernel<M>), g, dim3(64), 0, 0, rgb, id, t, W, H); }));
+    MODE_CASE(0) MODE_CASE(1) MODE_CASE(2) MODE_CASE(3) MODE_CASE(4) MODE_CASE(5) MODE_CASE(6) MODE_CASE(7)
+  }
   printf("the same with tiles of 16 lanes x 4 rows (32 x 4 pixels at P=2: full 128-byte lines of id and t):\n");
 #define CASEW(P, NT, WPW, T) { dim3 g((W / (16 * P * T) + WPW - 1) / WPW, H / 4); \
     float us = time_us([&] { hipLaunchKernelGGL((store_kernel<P, NT, 16>), g, dim3(64 * WPW), 0, 0, rgb, id, t, W, H, T); }); \
