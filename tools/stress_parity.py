@@ -57,7 +57,9 @@ for seed in range(first, first + count):
                 bad += 1
                 print("MISMATCH seed", seed, kind, "brute force vs ORACLE", W, H, spp,
                       {k: int((~((ref[k] == r[k]) | (np.isnan(ref[k]) & np.isnan(r[k])))).sum()) for k in ("id", "t", "rgb")}, flush=True)
-        for mode in ((5, 2) if kind == "small" else (2,)):
+        # mode 5 three times over: from the second repeat of a view the small-scene launcher starts the frame at the row
+        # where the geometry begins (mrt_small.hip, small_first_row), and the order must not show
+        for mode in ((5, 5, 5, 2) if kind == "small" else (2,)):
             ctx.set_cull(mode); g = ctx.render(cam, W, H, spp=spp, rank=part[0], num_ranks=part[1], strip_rows=part[2])
             ok = all(np.array_equal(g[k], ref[k], equal_nan=True) for k in ("id", "t", "rgb")) and \
                  all(g["stats"][k] == ref["stats"][k] for k in ("primary_rays", "shadow_rays", "hit_pixels", "occluded"))
