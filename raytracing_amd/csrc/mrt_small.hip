@@ -878,10 +878,13 @@ static int small_first_row(const SmallArgs &S, int ns, int nt, int P, int lx, in
   const float rw = 1.0f / float(S.A.W), rh = 1.0f / float(S.A.H);
   std::vector<int> cand((size_t)tiles_y, 0);
   long total = 0;
+  // a bounded amount of host work whatever the frame: every xs-th column of tiles (the rule below only compares counts)
+  const long work = (long)tiles_x * tiles_y * (ns + nt > 0 ? ns + nt : 1);
+  const int xs = int(work / 2000000L) + 1;
   for (int y = 0; y < tiles_y; ++y) {
     const float vm = (float(y * LY) + 0.5f * float(LY - 1)) * rh;
     int c = 0;
-    for (int x = 0; x < tiles_x; ++x) {
+    for (int x = 0; x < tiles_x; x += xs) {
       const float um = (float(x * TW) + 0.5f * float(TW - 1)) * rw;
       bool any = false;
       for (int i = 0; i < ns && !any; ++i)
