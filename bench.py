@@ -366,8 +366,8 @@ def main():
             kernel_name, kernel_desc = "render_kernel", "render_kernel (brute force: every ray x every primitive)"
         elif small:
             kernel_name = "render_small_kernel"
-            kernel_desc = ("render_small_kernel: 16x8-pixel tiles, 2 pixels per lane, per-tile culling (cone test for "
-                           "spheres, screen-space edge functions for triangles) + exact tests")
+            kernel_desc = ("render_small_kernel: 16x8-pixel tiles, 2 pixels per lane, per-tile culling (screen rectangles "
+                           "for spheres, screen-space edge functions for triangles) + exact tests")
         else:
             kernel_name = "render_cull_kernel"
             kernel_desc = ("render_cull_kernel: per-tile conservative culling over the kd-ordered primitive "

@@ -10,8 +10,9 @@
 //     exact tests (o - c, |o - c|^2 - r^2, k - n.o) in registers and tests the primitive's bound against the
 //     tile; the survivors' terms are broadcast with v_readlane -- no memory access in the sphere loops, one
 //     64-byte scalar load per surviving triangle;
-//   * spheres are bounded with the cone / swept-ball tests of mrt_cull_common.h, triangles with SCREEN-SPACE
-//     EDGE FUNCTIONS.  For a triangle (plane n, k; edge planes m_i, c_i) and a ray o + t d accepted by the
+//   * primary rays: a sphere is bounded by its SCREEN RECTANGLE (the tile centres whose padded tile can hold a ray
+//     that touches it: four compares per tile; small_primary_functions), shadow rays by the swept-ball tests of
+//     mrt_cull_common.h; triangles by SCREEN-SPACE EDGE FUNCTIONS.  For a triangle (plane n, k; edge planes m_i, c_i) and a ray o + t d accepted by the
 //     exact test (t > 0), e_i(p) = (w_i . d) / (n . d) with w_i = (m_i.o - c_i) n + (k - n.o) m_i, and
 //     sign(n.d) = sign(k - n.o); w_i . d is affine in the pixel coordinates, so its maximum over the tile is
 //     its value at the tile centre plus a constant.  If that maximum is below a margin for one edge, no ray
@@ -21,6 +22,8 @@
 //     hit point p meets the plane is affine in p, for directional and for point lights, and is bounded over
 //     the ball around the tile's hit points; these functions depend on scene and lights only and are built
 //     at upload (mrt_scene_build.h, shadow_functions);
+//   * a wave is one workgroup; rows of tiles are launched starting where a view's geometry begins once the view has
+//     been seen before (small_first_row), and a tile no ray of which can hit anything takes a sky-only path;
 //   * u = col / W and v = row / H come from two tables computed once per frame size with the same IEEE
 //     division (uv_table_kernel) instead of 1 + P divisions per lane.
 //
