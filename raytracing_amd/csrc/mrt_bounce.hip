@@ -108,7 +108,7 @@ __device__ __forceinline__ float prm_of(const SmallArgs &s, int f, int lane) { r
 #ifdef MRT_TIMELINE
 // Diagnostic build only (make variant DEFS=-DMRT_TIMELINE; tools/timeline_cull.py REF): per tile the 100 MHz real-time
 // clock at entry and exit of its wave, the shader clock it lived, chain steps | loop iterations.
-enum { TLB_WORDS = 4, TLB_MAX_WAVES = 1 << 18 };
+enum { TLB_WORDS = 8, TLB_MAX_WAVES = 1 << 17 }; // 4..7: cycles in closest hit | light | push + bounce | fold
 __device__ unsigned long long g_timeline_bounce[TLB_WORDS * TLB_MAX_WAVES];
 extern "C" int mrt_diag_timeline_bounce(unsigned long long *host_out, size_t words)
 {
@@ -138,6 +138,7 @@ __device__ __forceinline__ void render_bounce_body(const Args &S)
   const int tile_y = tile / tiles_x, tile_x = tile - tile_y * tiles_x;
 #ifdef MRT_TIMELINE
   const unsigned long long tl_rt0 = __builtin_amdgcn_s_memrealtime(), tl_c0 = __builtin_amdgcn_s_memtime();
+  unsigned long long tl_acc[4] = {0, 0, 0, 0};
 #endif
   const int col = tile_x * 8 + tx;
   const int lrow = tile_y * 8 + ty;
@@ -326,7 +327,14 @@ __device__ __forceinline__ void render_bounce_body(const Args &S)
     // the waiting lanes take one step against every primitive.  Waiting fills the expensive iterations: most
     // chains end at level 0 or 1.
     const int deep_threshold = A.s_cap > 0 ? A.s_cap : 64;
+#ifdef MRT_TIMELINE
+    unsigned long long tl_last = __builtin_amdgcn_s_memtime();
+#define TLB_MARK(k) do { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); tl_acc[k] += now_ - tl_last; tl_last = now_; } while (0)
+#else
+#define TLB_MARK(k) do { } while (0)
+#endif
     while (true) {
+      TLB_MARK(3);
       const unsigned long long wmask = __ballot(work);
       if (!wmask) break;
       const unsigned long long m0 = __ballot(work && depth == 0);
@@ -486,6 +494,7 @@ __device__ __forceinline__ void render_bounce_body(const Args &S)
         finish = true;
       }
 
+      TLB_MARK(0);
       // ---- hit record (core/sphere.cuh:45-47, core/triangle.cuh:96-97) ----
       float hpx = 0.0f, hpy = 0.0f, hpz = 0.0f, hnx = 0.0f, hny = 0.0f, hnz = 0.0f;
       if (have_hit) {
@@ -710,6 +719,7 @@ __device__ __forceinline__ void render_bounce_body(const Args &S)
         }
       }
 
+      TLB_MARK(1);
       // ---- push the level; continue with the bounced ray or end the chain ----
       if (have_hit) {
         const float *m = sc.mat_rgb + 3 * best_obj;
@@ -749,6 +759,7 @@ __device__ __forceinline__ void render_bounce_body(const Args &S)
         }
       }
 
+      TLB_MARK(2);
       // ---- a chain ended: fold it (src/main.cu:91-98, innermost level first), add it to the pixel, next sample ----
       if (__any(finish)) {
         float cr = inr, cg = ing, cb = inb;
@@ -787,6 +798,7 @@ __device__ __forceinline__ void render_bounce_body(const Args &S)
     unsigned long long *tlp = g_timeline_bounce + (size_t)TLB_WORDS * tile;
     tlp[0] = tl_rt0; tlp[1] = __builtin_amdgcn_s_memrealtime(); tlp[2] = __builtin_amdgcn_s_memtime() - tl_c0;
     tlp[3] = (unsigned long long)n_steps | ((unsigned long long)n_iter << 32);
+    for (int k = 0; k < 4; ++k) tlp[4 + k] = tl_acc[k];
   }
 #endif
   if (A.stats) {

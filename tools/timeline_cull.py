@@ -35,11 +35,12 @@ def main():
     L = capi.libmrt()
     tx, ty = (W + 7) // 8, (H + 7) // 8
     nw = tx * ty
-    buf = np.zeros(nw * 4, dtype=np.uint64)
+    words = 8 if cfg == "REF" else 4
+    buf = np.zeros(nw * words, dtype=np.uint64)
     diag = L.mrt_diag_timeline_bounce if cfg == "REF" else L.mrt_diag_timeline_cull
     diag.argtypes = [C.c_void_p, C.c_size_t]
     assert diag(buf.ctypes.data, buf.size) == 0
-    t = buf.reshape(nw, 4).astype(np.int64)
+    t = buf.reshape(nw, words).astype(np.int64)
     rt0 = t[:, 0].min()
     start, end = (t[:, 0] - rt0) * 10.0 / 1e3, (t[:, 1] - rt0) * 10.0 / 1e3   # us
     life_us = end - start
@@ -60,6 +61,13 @@ def main():
            "profile[t_us, resident waves, started so far]": prof,
            "mean life_us by tile row (every %d-th)" % max(1, ty // 16): [round(float(x), 1) for x in rows.mean(axis=1)[::max(1, ty // 16)]],
            "max life_us by tile row": [round(float(x), 1) for x in rows.max(axis=1)[::max(1, ty // 16)]]}
+    if cfg == "REF":  # where the cycles of the longest waves go (mrt_bounce.hip, TLB_MARK)
+        top = np.argsort(-life_us)[:64]
+        ph = t[top, 4:8].sum(axis=0).astype(float)
+        out["longest 64 waves: share of loop cycles in closest hit | light | push + bounce | fold + loop head"] = [round(float(x), 3) for x in ph / ph.sum()]
+        out["longest 64 waves: cycles per iteration"] = round(float(t[top, 4:8].sum() / (t[top, 3] >> 32).sum()), 0)
+        allp = t[:, 4:8].sum(axis=0).astype(float)
+        out["all waves: share of loop cycles, same four"] = [round(float(x), 3) for x in allp / max(allp.sum(), 1.0)]
     txt = json.dumps(out, indent=1)
     print(txt)
     if len(sys.argv) > 2:
