@@ -122,7 +122,9 @@ hipError_t launch_render_small(const RenderArgs &args, const SmallHost &host, hi
 
 // Kernel arguments of the small-scene kernels: the common ones plus everything a wave needs about "its"
 // primitives (lane = primitive: spheres first, then triangles) before the first exact test, [field][lane]:
-//   sphere lanes:   0-2 centre - origin, 3 primary cull radius, 4-6 origin - centre, 7 |o - c|^2 - r^2, 8 object
+//   sphere lanes:   0-3 screen rectangle (lo u, hi u, lo v, hi v) of the tile centres whose padded tile can hold a ray
+//                   that touches the sphere; 4-6 origin - centre, 7 |o - c|^2 - r^2, 8 object; 9-11 centre - origin and
+//                   12 primary cull radius (the cone test of the bounce kernels' primary iterations)
 //   triangle lanes: 0-11 four functions (3 edges + plane side) x (W0', Wh, Wv): "W0' + um Wh + vm Wv < 0" at the
 //                   tile centre (um, vm) means that no ray of the padded tile passes that test;
 //                   12 k - n.o, 13 object
