@@ -535,6 +535,36 @@ def test_small_scenes_rendered_again_and_again(gpu_ctx, seed):
     gpu_ctx.set_cull(1)
 
 
+@pytest.mark.parametrize("spp", [1, 121])
+def test_geometry_in_the_last_rows_rendered_again_and_again(gpu_ctx, spp):
+    """A view whose geometry sits in the LAST rows of tiles (a few spheres and a triangle high in the picture, one small
+    sphere near the bottom): the remembered-view rule then starts the launch deep in the frame and wraps around over many
+    rows.  Every repeat equals the oracle bit for bit."""
+    # (row 0 of the buffers is v = 0, the bottom of the picture: "last rows" are the top)
+    sp = np.float32([[-2.0, 3.2, -14.0, 0.6], [0.5, 3.4, -12.0, 0.5], [2.5, 3.1, -15.0, 0.7], [0.0, -3.9, -16.0, 0.15]])
+    tv = np.float32([[[-6.0, 4.0, -10.0], [6.0, 4.0, -10.0], [0.0, 3.6, -22.0]]])
+    n = len(sp) + len(tv)
+    kind, rgb = scenes._cycle_materials(n)
+    cam = {"look_from": (0.0, 0.0, 0.0), "look_at": (0.0, 0.0, -1.0), "up": (0.0, 1.0, 0.0), "vfov": 40.0}
+    lights = [(capi.LIGHT_DIRECTIONAL, (0.3, 1.0, -0.2), (3.0, 3.0, 3.0)), (capi.LIGHT_POINT, (1.0, -2.0, -10.0), (1.0, 0.8, 0.6))]
+    spec = scenes.SceneSpec("low_geometry", sp, np.arange(len(sp)), tv, len(sp) + np.arange(len(tv)), kind, rgb, lights, cam)
+    W, H = (512, 384) if spp == 1 else (128, 160)
+    gpu_ctx.set_cull(5)
+    gpu_ctx.upload(spec.flatten())
+    cam12 = spec.cam12(W / H)
+    r = O.Scene.from_spec(spec).render(cam12, W, H, spp=spp, nthreads=8)
+    ids = r["id"]
+    rows_hit = np.nonzero((ids >= 0).any(axis=1))[0]
+    assert rows_hit.size and np.median(rows_hit) > 0.6 * H, "the scene is meant to sit in the last rows of the frame"
+    try:
+        for i in range(4):
+            g = gpu_ctx.render(cam12, W, H, spp=spp)
+            assert_frame_parity(g, r, f"low geometry, spp {spp}, repeat {i}")
+            assert_stats_parity(g["stats"], r["stats"])
+    finally:
+        gpu_ctx.set_cull(1)
+
+
 def test_default_scene_1080p_repeated(gpu_ctx):
     """BASELINE config 2 rendered five times in a row, the way the bench does: from the third frame on the launch
     starts in the row where the default scene's geometry begins (the tuned order must be in use, and invisible)."""
