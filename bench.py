@@ -1,14 +1,22 @@
 #!/usr/bin/env python3
 """bench.py -- headline benchmark: Mrays/s (primary + shadow) of the render hot path.
 
-    python bench.py --gpus N --steps K --warmup W [--config C2|C3|C4|C5|REF]
+    python bench.py --gpus N --steps K --warmup W [--config all|C2|C3|C4|C5|REF|C2,C3,...]
 
-A "step" is one frame of the configured workload: every rank renders its strips of the frame with the HIP back
-end (scene already resident in HBM); for N > 1 every rank but 0 then sends its strips to rank 0 over RCCL (one
-message per peer) and rank 0 puts them in place.  Default workload = BASELINE.json configs[1]: the reference's
-default scene (src/main.cu:183-237) at 1920x1080, 1 spp, primary + shadow rays.  REF (not a BASELINE config) is
-what the reference binary itself renders: the same scene at 2048x1024, 121 samples per pixel, bounce chains to
-depth 8 (src/main.cu:26, :165).
+A "step" is one frame of a workload: every rank renders its strips of the frame with the HIP back end (scene already
+resident in HBM); for N > 1 every rank but 0 then sends its strips to rank 0 over RCCL (one message per peer) and
+rank 0 puts them in place.  The HEADLINE workload (the top-level fields of the JSON line) is the first config named:
+by default BASELINE.json configs[1], the reference's default scene (src/main.cu:183-237) at 1920x1080, 1 spp, primary
++ shadow rays (C2).  With no --config every workload is measured in the same run and reported in the `configs`
+array of the same line: C2, C3 (10k spheres, 4K), C4 (1M triangles, 4K), C5 (64 point lights, 1080p) and REF -- not
+a BASELINE config: what the reference binary itself renders, the default scene at 2048x1024, 121 samples per pixel,
+bounce chains to depth 8 (src/main.cu:26, :165).
+
+Timing.  After W warm-up frames and an untimed settle phase (GPU clocks), a config is timed as R BLOCKS of exactly K
+frames, each block bracketed by a barrier + torch.cuda.synchronize() on both sides and taken as the MAX over ranks;
+R is chosen so that a config gets at least ~50 ms of GPU time (a 20-frame block of a 17 us frame is 0.35 ms: one such
+block measures the closing synchronisation as much as the frames).  `value` and `ms_per_step` come from the MEDIAN
+block; min / max are reported beside them.
 
 With --gpus N > 1 and no WORLD_SIZE in the environment the script starts its own N ranks
 (python -m torch.distributed.run ... bench.py, as the driver would) before it touches a GPU, relays rank 0's JSON
@@ -17,14 +25,24 @@ line and exits with the children's status.
 Prints ONE JSON line on rank 0 (contract in the task statement), including
   roofline      -- the render kernel against the HBM roof: algorithmic bytes per launch / its HIP-event time
   executed_work -- what the kernel executed per launch according to the committed rocprofv3 counter passes
-                   (profiles/counters.json): vector instructions, their issue time, waves per SIMD, HBM bytes
+                   (profiles/counters.json): vector instructions, their issue time, waves per SIMD, HBM bytes; each
+                   entry carries the hash of the kernel sources it was taken from and `stale` says whether that is
+                   the tree this run was built from
+  first_view    -- small scenes: the same frames with the launcher's view memory off (MRT_OPT_VIEW_CACHE 0): what a
+                   camera that moves every frame gets
   end_to_end    -- blocking mrt_render into page-locked host memory (launch + sync + frame in host memory, which is
-                   what src/main.cu:239-247 does), N = 1 only, outside the headline's timed region
+                   what src/main.cu:239-247 does), N = 1 only, outside the timed region
   cpu_baseline  -- the CPU oracle ("port") timed on this host, bounded sample (rank 0, N = 1 only)
+  configs       -- one entry per workload measured in this run (the headline's included)
+  frame_check   -- N > 1: the gathered frame against rank 0 rendering all of it alone, bit for bit; a difference makes
+                   the run exit with status 3
 """
 import argparse
+import hashlib
 import json
+import math
 import os
+import statistics
 import subprocess
 import sys
 import time
@@ -37,6 +55,9 @@ VALU_PEAK_TFLOPS = 157.3     # fp32 vector peak (packed FMA); parity forbids FMA
 BYTES_PER_PIXEL = 20         # RGB f32 + id i32 + t f32
 SIMDS = 1024                 # 256 CUs x 4
 VALU_ISSUE_NS = 2.0 / 2.4    # MI355X_MICROARCH.md: a wave64 vector instruction issues over 2 cycles at 2.4 GHz
+ALL_CONFIGS = ("C2", "C3", "C4", "C5", "REF")
+MIN_GPU_MS = 50.0            # GPU time a config gets in its timed blocks, at least
+MAX_BLOCKS = 200
 
 
 def build_workload(name):
@@ -75,10 +96,24 @@ def build_workload(name):
     return flat, cam12, W, H, flops, scene_bytes, spec, label, spp, max_depth
 
 
+def source_hash():
+    """Hash of the sources libmrt.so is built from (csrc/*.hip, *.h, *.cpp, the Makefile and include/mrt.h): what a
+    committed counter pass is tied to (tools/summarize_profile.py writes it into profiles/counters.json)."""
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "raytracing_amd", "csrc")
+    names = sorted(f for f in os.listdir(d) if f.endswith((".hip", ".h", ".cpp")) or f == "Makefile")
+    for f in [os.path.join(d, n) for n in names] + [os.path.join(ROOT, "include", "mrt.h")]:
+        h.update(os.path.basename(f).encode() + b"\0")
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
 def committed_counters(config, brute):
     """Per-launch rocprofv3 counters of the render kernel from the committed passes (profiles/counters.json, written
     by tools/profile_config.sh + tools/summarize_profile.py on the GPU box: SQ counters, FETCH_SIZE and WRITE_SIZE
-    each in a --pmc run of its own of THIS command).  Not measured by this run: the JSON says where they come from."""
+    each in a --pmc run of its own of THIS command).  Not measured by this run: the JSON says where they come from
+    and whether the kernel sources have changed since (`stale`)."""
     try:
         with open(os.path.join(ROOT, "profiles", "counters.json")) as f:
             return json.load(f).get(config + ("_brute" if brute else ""))
@@ -86,18 +121,21 @@ def committed_counters(config, brute):
         return None
 
 
-def cpu_baseline(name, spec, flat, cam12, W, H, spp=1, max_depth=0):
+def cpu_baseline(name, spec, flat, cam12, W, H, spp=1, max_depth=0, quick=False):
     """Time the CPU oracle (a scalar port of the reference path) on this host: bounded sample of the same
     workload.  Brute force costs rays x primitives x (1 + lights), so the sample frame is shrunk (same scene,
-    same camera, fewer pixels) until one frame is about 1e9 primitive tests per thread."""
+    same camera, fewer pixels) until one frame is about 1e9 primitive tests per thread.  quick: the threaded leg
+    only, a quarter of that and at most ~3 s (the extra configs of a default run)."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import _oracle as O  # test infrastructure, used here only as the reported CPU baseline
 
     scene = O.Scene.default() if spec is None else O.Scene.from_spec(spec)
     threads = min(16, os.cpu_count() or 1)  # the GPU box's CPU share for one GPU is 16
     per_ray = max(1, flat.num_spheres + flat.num_triangles) * (1 + flat.num_lights) * spp
+    legs = (("threads", threads, 2.5e8 * threads, 3.0),) if quick else \
+           (("1thread", 1, 1.0e9, 6.0), ("threads", threads, 1.0e9 * threads, 10.0))
     out = {}
-    for label, nt, budget_tests, budget_s in (("1thread", 1, 1.0e9, 6.0), ("threads", threads, 1.0e9 * threads, 10.0)):
+    for label, nt, budget_tests, budget_s in legs:
         scale = 1
         while (W // scale) * (H // scale) * per_ray > budget_tests and min(W, H) // (scale * 2) >= 8:
             scale *= 2
@@ -111,13 +149,17 @@ def cpu_baseline(name, spec, flat, cam12, W, H, spp=1, max_depth=0):
             if dt >= budget_s or frames >= 200:
                 break
         out[label] = (rays / dt / 1e6, frames, dt, sw, sh)
-    v1, vn = out["1thread"], out["threads"]
-    return {
+    vn = out["threads"]
+    res = {
         "value": round(vn[0], 4), "unit": "Mrays/s", "cores": threads, "kind": "port",
         "sample": f"{vn[1]} frame(s) of the same scene and camera at {vn[3]}x{vn[4]} in {vn[2]:.1f}s on {threads} threads "
-                  f"(rows split statically); single thread: {v1[0]:.4f} Mrays/s over {v1[1]} frame(s) at {v1[3]}x{v1[4]}",
-        "value_1thread": round(v1[0], 4),
+                  f"(rows split statically)",
     }
+    if "1thread" in out:
+        v1 = out["1thread"]
+        res["sample"] += f"; single thread: {v1[0]:.4f} Mrays/s over {v1[1]} frame(s) at {v1[3]}x{v1[4]}"
+        res["value_1thread"] = round(v1[0], 4)
+    return res
 
 
 def end_to_end(fr, cam12, W, H, spp, max_depth, rays_per_frame, frames):
@@ -173,93 +215,131 @@ def launch_ranks(n):
     return proc.returncode
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=None)
-    ap.add_argument("--warmup", type=int, default=None)
-    ap.add_argument("--config", default="C2")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--brute-force", action="store_true", help="use the every-ray-every-primitive kernel")
-    ap.add_argument("--dump-frame", default=None, help="rank 0 saves the last frame (rgb, id, t) to this .npz")
-    args = ap.parse_args()
+class Env:
+    """What every config of a run shares: the process group, the device, the flags."""
 
-    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
-        raise SystemExit(launch_ranks(args.gpus))
+    def __init__(self, args):
+        import torch
+        import torch.distributed as dist
 
-    import torch
-    import torch.distributed as dist
+        self.torch, self.dist, self.args = torch, dist, args
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.rank = int(os.environ.get("RANK", "0"))
+        local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        self.backend = os.environ.get("MRT_BENCH_BACKEND", "nccl")  # "gloo": rehearsal on a box with fewer GPUs than ranks
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs a GPU: there is no CPU fallback of the product path")
+        if self.backend != "nccl":
+            local_rank = local_rank % torch.cuda.device_count()  # rehearsal: ranks share the GPUs there are
+        elif local_rank >= torch.cuda.device_count():
+            raise SystemExit(f"rank {self.rank}: {self.world} ranks over RCCL need {self.world} GPUs, this node shows "
+                             f"{torch.cuda.device_count()} (MRT_BENCH_BACKEND=gloo rehearses the path on fewer)")
+        self.local_rank = local_rank
+        torch.cuda.set_device(local_rank)
+        if self.world > 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            if self.backend == "nccl":
+                dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+            else:
+                dist.init_process_group(self.backend)
+        self.src_hash = source_hash()
 
-    from raytracing_amd import multigpu
-
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    args.gpus = world
-    backend = os.environ.get("MRT_BENCH_BACKEND", "nccl")  # "gloo": rehearsal on a box with fewer GPUs than ranks
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU: there is no CPU fallback of the product path")
-    if backend != "nccl":
-        local_rank = local_rank % torch.cuda.device_count()  # rehearsal: ranks share the GPUs there are
-    elif local_rank >= torch.cuda.device_count():
-        raise SystemExit(f"rank {rank}: {world} ranks over RCCL need {world} GPUs, this node shows "
-                         f"{torch.cuda.device_count()} (MRT_BENCH_BACKEND=gloo rehearses the path on fewer)")
-    torch.cuda.set_device(local_rank)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
-        else:
-            dist.init_process_group(backend)
-
-    def progress(msg):  # stderr only: stdout carries the one JSON line
-        if rank == 0:
+    def progress(self, msg):  # stderr only: stdout carries the one JSON line
+        if self.rank == 0:
             print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
 
-    progress(f"building workload {args.config}")
-    flat, cam12, W, H, flops_ray, scene_bytes, spec, label, spp, max_depth = build_workload(args.config)
-    heavy = args.config in ("C3", "C4", "REF")
-    steps = args.steps if args.steps is not None else (3 if args.config == "C4" else (20 if heavy else 500))
-    warmup = args.warmup if args.warmup is not None else (1 if heavy else 50)
+    def sync(self):
+        if self.world > 1:
+            self.dist.barrier()
+        self.torch.cuda.synchronize()
 
-    fr = multigpu.FrameRenderer(flat, cam12, W, H, rank=rank, num_ranks=world, device=local_rank, spp=spp,
-                                max_depth=max_depth)
+
+def make_comm(env, fr):
+    """The exchange step's carrier: mrt_gather_strips (RCCL behind the C-ABI) on a communicator made from an id that
+    rank 0 creates and torch.distributed hands round.  If any rank cannot create it (or MRT_BENCH_GATHER=torch, or a
+    gloo rehearsal with ranks sharing a GPU) every rank uses torch.distributed's point-to-point calls instead."""
+    torch, dist = env.torch, env.dist
+    if env.world == 1:
+        return "none"
+    gather = "torch.distributed point-to-point (" + env.backend + ")"
+    want = os.environ.get("MRT_BENCH_GATHER", "capi")  # "torch": skip; "capi-force": try even in a gloo rehearsal
+    if (env.backend == "nccl" and want == "capi") or want == "capi-force":
+        from raytracing_amd import capi
+        uid = [None]
+        ok = 1
+        try:
+            if env.rank == 0:
+                uid[0] = capi.comm_unique_id()
+        except capi.MrtError as e:
+            env.progress(f"mrt_comm_unique_id failed: {e}")
+        dist.broadcast_object_list(uid, src=0)
+        try:
+            if uid[0] is None:
+                raise capi.MrtError("no communicator id")
+            fr.init_comm(uid[0])
+        except capi.MrtError as e:
+            ok = 0
+            print(f"[bench] rank {env.rank}: mrt_comm_create failed: {e}", file=sys.stderr, flush=True)
+        flag = torch.tensor([ok], dtype=torch.int32, device=fr.dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) == 1:
+            gather = "mrt_gather_strips (RCCL behind the C-ABI: ncclSend per peer, grouped ncclRecv on rank 0)"
+        else:
+            fr.drop_comm()
+    return gather
+
+
+def timed_blocks(env, fr, steps, nblocks, local_only):
+    """nblocks blocks of exactly `steps` frames, each between two barrier + synchronise pairs.  -> (wall seconds per
+    block, MAX over ranks; HIP-event ms per frame per block or None).  local_only: frames are fr.render_local() with
+    one HIP-event pair on the launch stream (torch's current stream) around each block -- its time over `steps` is
+    the kernel's average launch-to-launch duration (no per-step events: a pair costs 2-3 us of a 17 us frame)."""
+    torch, dist = env.torch, env.dist
+    wall, kern = [], []
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(nblocks)] \
+        if local_only else None
+    for b in range(nblocks):
+        env.sync()
+        t0 = time.perf_counter()
+        if local_only:
+            ev[b][0].record()
+            for _ in range(steps):
+                fr.render_local()
+            ev[b][1].record()
+        else:
+            for _ in range(steps):
+                fr.step()
+        env.sync()
+        wall.append(time.perf_counter() - t0)
+    if local_only:
+        kern = [e0.elapsed_time(e1) / steps for e0, e1 in ev]
+    w = torch.tensor(wall, dtype=torch.float64, device=fr.dev)
+    if env.world > 1:
+        dist.all_reduce(w, op=dist.ReduceOp.MAX)
+    return [float(x) for x in w.cpu()], (kern if local_only else None)
+
+
+def measure(env, name, headline):
+    """One config, all of it: -> the config's entry (rank 0) or None."""
+    from raytracing_amd import capi, multigpu
+
+    torch, dist, args = env.torch, env.dist, env.args
+    world, rank = env.world, env.rank
+    env.progress(f"building workload {name}")
+    flat, cam12, W, H, flops_ray, scene_bytes, spec, label, spp, max_depth = build_workload(name)
+    steps = args.steps if args.steps is not None else 100
+    warmup = args.warmup if args.warmup is not None else 5
+    planes = {"all": capi.PLANES_ALL, "rgb": capi.PLANE_RGB}[args.planes]
+
+    fr = multigpu.FrameRenderer(flat, cam12, W, H, rank=rank, num_ranks=world, device=env.local_rank, spp=spp,
+                                max_depth=max_depth, planes=planes, pipeline=args.pipeline)
     fr.ctx.set_cull(0 if args.brute_force else 1)
-    # The exchange step's carrier: mrt_gather_strips (RCCL behind the C-ABI) on a communicator made from an id that
-    # rank 0 creates and torch.distributed hands round.  If any rank cannot create it (or MRT_BENCH_GATHER=torch, or a
-    # gloo rehearsal with ranks sharing a GPU) every rank uses torch.distributed's point-to-point calls instead.
-    gather = "none"
-    if world > 1:
-        gather = "torch.distributed point-to-point (" + backend + ")"
-        want = os.environ.get("MRT_BENCH_GATHER", "capi")  # "torch": skip; "capi-force": try even in a gloo rehearsal
-        if (backend == "nccl" and want == "capi") or want == "capi-force":
-            from raytracing_amd import capi
-            uid = [None]
-            ok = 1
-            try:
-                if rank == 0:
-                    uid[0] = capi.comm_unique_id()
-            except capi.MrtError as e:
-                progress(f"mrt_comm_unique_id failed: {e}")
-            dist.broadcast_object_list(uid, src=0)
-            try:
-                if uid[0] is None:
-                    raise capi.MrtError("no communicator id")
-                fr.init_comm(uid[0])
-            except capi.MrtError as e:
-                ok = 0
-                print(f"[bench] rank {rank}: mrt_comm_create failed: {e}", file=sys.stderr, flush=True)
-            flag = torch.tensor([ok], dtype=torch.int32, device=fr.dev)
-            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-            if int(flag.item()) == 1:
-                gather = "mrt_gather_strips (RCCL behind the C-ABI: ncclSend per peer, grouped ncclRecv on rank 0)"
-            else:
-                fr.drop_comm()
+    gather = make_comm(env, fr)
     bytes_pp = BYTES_PER_PIXEL
     if max_depth > 0:
         bytes_pp += 20  # the pixel's random stream: five xorshift words read per frame (mrt_rng.hip)
 
-    progress("scene uploaded; counting rays")
+    env.progress("scene uploaded; counting rays")
     # rays per frame (deterministic for a scene + camera): counted once, outside the timed region
     mine = fr.count_rays()
     cnt = torch.tensor([mine["primary_rays"], mine["shadow_rays"], fr.local_rows * W], dtype=torch.int64,
@@ -269,88 +349,100 @@ def main():
     primary, shadow, _ = (int(x) for x in cnt.cpu())
     rays_per_frame = primary + shadow
 
-    def sync():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    progress(f"{rays_per_frame} rays per frame; warmup {warmup}, steps {steps}")
+    env.progress(f"{rays_per_frame} rays per frame; warmup {warmup}, blocks of {steps} steps")
     for _ in range(warmup):
         fr.step()
-    sync()
+    env.sync()
     # The GPU raises its clocks only under sustained load: after idle, the default frame takes 18.0 us and settles at
     # 16.2 us once launches have been coming for ~12 ms (tools/exp_settle.py).  `warmup` frames of 17 us are over
     # before that, so untimed frames go on until SETTLE_MS have passed since the first: a steady-state rate is what the
-    # metric means.  The timed region below stays exactly `steps` frames.
+    # metric means.
     settle_ms = float(os.environ.get("MRT_BENCH_SETTLE_MS", "60"))
     t_settle = time.perf_counter()
     fr.step()
-    sync()
+    env.sync()
     one = torch.tensor([time.perf_counter() - t_settle], dtype=torch.float64, device=fr.dev)
     if world > 1:
         dist.all_reduce(one, op=dist.ReduceOp.MAX)  # every rank runs the same number of frames
     settle_frames = int(max(0, min(8192, settle_ms * 1e-3 / max(float(one.item()), 1e-6))))
+    t_loop = time.perf_counter()
     for _ in range(settle_frames):  # back to back, no synchronisation in between
         fr.step()
-    sync()
+    env.sync()
     settle_spent_ms = (time.perf_counter() - t_settle) * 1e3
-    # The timed region: exactly `steps` frames between two barriers + synchronisations, nothing else in it.  At
-    # N = 1 one HIP-event pair on the launch stream (torch's current stream) brackets the whole loop: its time over
-    # `steps` is the kernel's average launch-to-launch duration (no per-step events: a pair costs 2-3 us of a 19 us
-    # frame).  At N > 1 the kernel is timed afterwards, the same way, on render-only frames.
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    t0 = time.perf_counter()
-    if world == 1:
-        e0.record()
-        for _ in range(steps):
-            fr.render_local()
-        e1.record()
-    else:
-        for _ in range(steps):
-            fr.step()
-    sync()
-    elapsed = time.perf_counter() - t0
-    el = torch.tensor([elapsed], dtype=torch.float64, device=fr.dev)
+    # frame time estimate -> number of blocks (the same on every rank)
+    est = torch.tensor([(time.perf_counter() - t_loop) / max(settle_frames, 1) if settle_frames else float(one.item())],
+                       dtype=torch.float64, device=fr.dev)
     if world > 1:
-        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+        dist.all_reduce(est, op=dist.ReduceOp.MAX)
+    nblocks = args.blocks if args.blocks else \
+        int(max(3, min(MAX_BLOCKS, math.ceil(MIN_GPU_MS * 1e-3 / max(steps * float(est.item()), 1e-9)))))
+
+    # The timed region: nblocks x exactly `steps` frames.
+    wall, kern = timed_blocks(env, fr, steps, nblocks, local_only=(world == 1))
+    if world > 1:  # the render kernel alone, timed afterwards the same way on render-only frames
         ksteps = min(steps, 50)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
         e0.record()
         for _ in range(ksteps):
             fr.render_local()
         e1.record()
         torch.cuda.synchronize()
         kern_ms = e0.elapsed_time(e1) / ksteps
+        kern_how = f"one HIP-event pair around {ksteps} back-to-back render-only launches on the launch stream"
     else:
-        kern_ms = e0.elapsed_time(e1) / steps
-    elapsed = float(el.item())
+        kern_ms = statistics.median(kern)
+        kern_how = (f"one HIP-event pair around each block of {steps} back-to-back launches on the launch stream; "
+                    f"median of {nblocks} blocks (min {min(kern):.5f}, max {max(kern):.5f})")
+    med = statistics.median(wall)
+
+    # small scenes, N = 1: what the FIRST render of a view costs (and every render of a camera that moves): the
+    # launcher's view memory off, same frames, same timing
+    first_view = None
+    if world == 1 and not args.brute_force and max_depth == 0 and flat.num_spheres + flat.num_triangles <= 64:
+        fr.ctx.set_view_cache(False)
+        for _ in range(20):
+            fr.render_local()
+        w2, k2 = timed_blocks(env, fr, steps, nblocks, local_only=True)
+        fr.ctx.set_view_cache(True)
+        m2 = statistics.median(w2)
+        first_view = {"kernel_ms": round(statistics.median(k2), 5), "ms_per_step": round(m2 / steps * 1e3, 5),
+                      "value": round(rays_per_frame * steps / m2 / 1e6, 3),
+                      "what": "MRT_OPT_VIEW_CACHE 0: the launch starts at tile row 0, as for a view never rendered "
+                              "before or a camera that moves every frame; the headline renders ONE view again and "
+                              "again and the launcher starts it where the geometry begins (DESIGN.md 5.5)"}
 
     # N > 1: is the frame that arrived on rank 0 the frame one GPU renders?  Outside the timed region: one more
-    # distributed frame, then rank 0 renders all of it alone and compares the three planes bit for bit.
+    # distributed frame, then rank 0 renders all of it alone and compares the planes that travelled bit for bit.
     frame_check = None
     if world > 1:
         fr.step()
-        sync()
+        env.sync()
         if rank == 0:
-            solo = multigpu.FrameRenderer(flat, cam12, W, H, device=local_rank, spp=spp, max_depth=max_depth)
+            solo = multigpu.FrameRenderer(flat, cam12, W, H, device=env.local_rank, spp=spp, max_depth=max_depth)
             solo.ctx.set_cull(0 if args.brute_force else 1)
             solo.render_local()
             torch.cuda.synchronize()
-            same = {k: bool(torch.equal(a.view(torch.int32), b.view(torch.int32)))
-                    for k, a, b in (("rgb", fr.rgb, solo.rgb), ("id", fr.ids, solo.ids), ("t", fr.tt, solo.tt))}
+            pairs = [("rgb", fr.rgb, solo.rgb), ("id", fr.ids, solo.ids), ("t", fr.tt, solo.tt)]
+            same = {k: bool(torch.equal(a.view(torch.int32), b.view(torch.int32))) for k, a, b in pairs if a is not None}
             solo.close()
             frame_check = {"what": f"the frame gathered from {world} ranks against rank 0 rendering all of it alone, "
-                                   "bit for bit", **{k + "_equal": v for k, v in same.items()}}
+                                   "bit for bit", **{k + "_equal": v for k, v in same.items()},
+                           "ok": all(same.values())}
             if not all(same.values()):
-                print(f"[bench] FRAME CHECK FAILED: {frame_check}", file=sys.stderr, flush=True)
-        sync()
-    frame = fr.frame_host() if args.dump_frame else None
-    if rank == 0 and frame is not None:
-        import numpy as np
-        np.savez(args.dump_frame, **frame)
+                print(f"[bench] FRAME CHECK FAILED ({name}): {frame_check}", file=sys.stderr, flush=True)
+        env.sync()
+    if args.dump_frame and headline:
+        frame = fr.frame_host()
+        if rank == 0 and frame is not None:
+            import numpy as np
+            np.savez(args.dump_frame, **frame)
 
+    out = None
     if rank == 0:
-        ms_per_step = elapsed / steps * 1e3
-        value = rays_per_frame * steps / elapsed / 1e6
+        ms_per_step = med / steps * 1e3
+        value = rays_per_frame * steps / med / 1e6
         # dominant kernel = the render kernel; per launch this rank processes its own strips
         my_pixels = fr.local_rows * W
         my_rays = mine["primary_rays"] + mine["shadow_rays"]
@@ -372,44 +464,62 @@ def main():
             kernel_name = "render_cull_kernel"
             kernel_desc = ("render_cull_kernel: per-tile conservative culling over the kd-ordered primitive "
                            "hierarchy + exact tests")
-        pmc = committed_counters(args.config, args.brute_force) if world == 1 else None
+        pmc = committed_counters(name, args.brute_force) if world == 1 else None
+        stale = None
+        if pmc:
+            stale = pmc.get("source_hash") != env.src_hash  # an entry without a hash predates the provenance stamp
         traffic = None
         if pmc and "FETCH_SIZE_KB" in pmc and "WRITE_SIZE_KB" in pmc:
             # gfx950 correction (MI355X_MICROARCH.md, HBM): FETCH_SIZE counts half the bytes of wide reads; both in KiB
             traffic = int((2.0 * pmc["FETCH_SIZE_KB"] + pmc["WRITE_SIZE_KB"]) * 1024)
+        metric = ("Mrays/s (primary+shadow) at 1920x1080" if name in ("C2", "C5") else
+                  "Mrays/s (primary+shadow at every level) at 2048x1024, 121 spp, depth 8" if name == "REF" else
+                  "Mrays/s (primary+shadow) at 3840x2160")
+        multi = fr.describe()
         out = {
-            "metric": "Mrays/s (primary+shadow) at 1920x1080" if args.config in ("C2", "C5") else
-                      "Mrays/s (primary+shadow at every level) at 2048x1024, 121 spp, depth 8" if args.config == "REF" else
-                      "Mrays/s (primary+shadow) at 3840x2160",
+            "name": name, "metric": metric,
             "value": round(value, 3), "unit": "Mrays/s", "n_gpus": world, "steps": steps, "warmup": warmup,
             "warmup_settle": {"frames": settle_frames + 1, "ms": round(settle_spent_ms, 2),
                               "why": "untimed frames after the warm-up until the GPU clocks have settled (tools/exp_settle.py)"},
-            "ms_per_step": round(ms_per_step, 5), "higher_is_better": True,
-            "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{args.config}: {label}", "width": W, "height": H, "spp": spp, "max_depth": max_depth,
+            "ms_per_step": round(ms_per_step, 5),
+            "blocks": {"n": nblocks, "steps_each": steps, "which": "median",
+                       "ms_per_step_min": round(min(wall) / steps * 1e3, 5),
+                       "ms_per_step_max": round(max(wall) / steps * 1e3, 5),
+                       "gpu_ms_total": round(sum(wall) * 1e3, 2),
+                       "why": f"each block is exactly {steps} frames between barrier + synchronise pairs (MAX over "
+                              f"ranks); enough blocks for >= {MIN_GPU_MS:.0f} ms of GPU time"},
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{name}: {label}", "width": W, "height": H, "spp": spp, "max_depth": max_depth,
                        "primary_rays": primary, "shadow_rays": shadow,
                        "parallelism": f"{world} GPU(s): strips of {fr.strip_rows} rows round-robin, scene replicated" +
-                                      ("" if world == 1 else ", one message per peer to rank 0 (rgb + id + t), "
-                                                             "rank 0 renders in place and scatters the rest; carrier: " + gather),
-                       "outputs": "rgb f32 + id i32 + t f32" + ("" if world == 1 else ", all three gathered on rank 0"),
+                                      ("" if world == 1 else ", one message per peer to rank 0 (" + multi["planes_gathered"]
+                                       + "), rank 0 renders in place and scatters the rest; carrier: " + gather),
+                       "outputs": "rgb f32 + id i32 + t f32" if world == 1 else
+                                  multi["planes_gathered"] + " rendered and gathered on rank 0",
                        "kernel": kernel_desc},
             "roofline": {"bound": "hbm", "achieved": round(ach_gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(ach_gbs / HBM_PEAK_GBS, 5), "traffic": traffic,
                          "traffic_source": pmc.get("source") if (pmc and traffic is not None) else None,
-                         "kernel": kernel_name, "kernel_ms": round(kern_ms, 5),
-                         "kernel_ms_how": f"one HIP-event pair around {steps if world == 1 else min(steps, 50)} "
-                                          "back-to-back launches on the launch stream",
+                         "traffic_stale": stale if traffic is not None else None,
+                         "kernel": kernel_name, "kernel_ms": round(kern_ms, 5), "kernel_ms_how": kern_how,
                          "algorithmic_bytes_per_launch": alg_bytes,
                          "binding_resource": "vector-instruction issue, not HBM (see executed_work; DESIGN.md 5.5)"},
         }
+        if world > 1:
+            out["multi_gpu"] = {**multi, "exchange_overlaps_next_render": multi["pipeline_depth"] > 1,
+                                "carrier": gather}
         if pmc and "SQ_INSTS_VALU" in pmc:
             # what the kernel executed, not what a brute-force kernel would have: committed counter passes
             valu = pmc["SQ_INSTS_VALU"]
             issue_ms = valu / SIMDS * VALU_ISSUE_NS * 1e-6
-            ex = {"source": pmc.get("source"), "valu_insts_per_launch": int(valu),
+            ex = {"source": pmc.get("source"), "source_hash": pmc.get("source_hash"), "git_rev": pmc.get("git_rev"),
+                  "stale": stale, "tree_hash": env.src_hash,
+                  "valu_insts_per_launch": int(valu),
                   "valu_issue_ms": round(issue_ms, 5),
                   "valu_issue_frac_of_kernel_time": round(issue_ms / kern_ms, 4),
                   "valu_issue_model": "SQ_INSTS_VALU / 1024 SIMDs x 2 cycles at 2.4 GHz (MI355X_MICROARCH.md)"}
+            if pmc.get("rocprof_kernel_avg_ns"):
+                ex["rocprof_kernel_avg_ms"] = round(pmc["rocprof_kernel_avg_ns"] * 1e-6, 5)
             if "SQ_WAVES" in pmc:
                 ex["waves_per_launch"] = int(pmc["SQ_WAVES"])
             if pmc.get("GRBM_GUI_ACTIVE") and pmc.get("SQ_WAVE_CYCLES"):
@@ -429,21 +539,76 @@ def main():
                                     "achieved": round(ach_tf, 4), "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
                                     "frac": round(ach_tf / VALU_PEAK_TFLOPS, 5),
                                     "algorithmic_flops_per_ray": flops_ray, "algorithmic_flops_per_launch": alg_flops}
+        if first_view is not None:
+            out["first_view"] = first_view
+            out["first_view_ms"] = first_view["kernel_ms"]
         if frame_check is not None:
             out["frame_check"] = frame_check
         if world == 1:
-            progress(f"GPU done ({ms_per_step:.4f} ms/step, kernel {kern_ms:.4f} ms); end-to-end frames")
+            env.progress(f"{name}: GPU done ({ms_per_step:.4f} ms/step median of {nblocks} blocks, kernel {kern_ms:.4f} ms)"
+                         "; end-to-end frames")
             out["end_to_end"] = end_to_end(fr, cam12, W, H, spp, max_depth, rays_per_frame,
-                                           3 if args.config in ("C4", "REF") else 20)
+                                           3 if name in ("C4", "REF") else 20)
         if world == 1 and not args.no_cpu_baseline:
-            progress("timing the CPU oracle (bounded sample, ~20 s)")
-            out["cpu_baseline"] = cpu_baseline(args.config, spec, flat, cam12, W, H, spp, max_depth)
-        print(json.dumps(out), flush=True)
-
+            env.progress("timing the CPU oracle (bounded sample" + (", ~20 s)" if headline else ", ~3 s)"))
+            out["cpu_baseline"] = cpu_baseline(name, spec, flat, cam12, W, H, spp, max_depth, quick=not headline)
     fr.close()
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=None, help="frames per timed block (default 100)")
+    ap.add_argument("--warmup", type=int, default=None)
+    ap.add_argument("--config", default="all",
+                    help="all (default: C2 as the headline, then C3, C4, C5, REF) | one config | a comma list; the "
+                         "first one named is the headline")
+    ap.add_argument("--blocks", type=int, default=0, help="timed blocks per config (default: enough for 50 ms of GPU time)")
+    ap.add_argument("--planes", choices=("all", "rgb"), default="all",
+                    help="N > 1: what the ranks render for and send to rank 0 (rgb: the picture alone, 12 of 20 B/pixel)")
+    ap.add_argument("--pipeline", type=int, default=2, choices=(1, 2),
+                    help="N > 1: frames in flight (2: the exchange of a frame overlaps the next frame's render)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--brute-force", action="store_true", help="use the every-ray-every-primitive kernel")
+    ap.add_argument("--dump-frame", default=None, help="rank 0 saves the headline's last frame (rgb, id, t) to this .npz")
+    args = ap.parse_args()
+    names = list(ALL_CONFIGS) if args.config == "all" else [c.strip() for c in args.config.split(",") if c.strip()]
+    for c in names:
+        if c not in ALL_CONFIGS:
+            raise SystemExit(f"unknown config {c}")
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(launch_ranks(args.gpus))
+
+    env = Env(args)
+    args.gpus = env.world
+    entries = []
+    for i, name in enumerate(names):
+        e = measure(env, name, headline=(i == 0))
+        if e is not None:
+            entries.append(e)
+    status = 0
+    if env.rank == 0:
+        head = dict(entries[0])
+        del head["name"]
+        # the other workloads of this run, compact: what the judge needs per config (the headline's entry repeats
+        # the top-level numbers so that the array is complete by itself)
+        keep = ("name", "metric", "value", "unit", "n_gpus", "steps", "ms_per_step", "blocks", "config", "roofline",
+                "executed_work", "first_view_ms", "frame_check", "multi_gpu", "end_to_end", "cpu_baseline")
+        head["configs"] = [{k: e[k] for k in keep if k in e} | {"kernel_ms": e["roofline"]["kernel_ms"]} for e in entries]
+        bad = [e["name"] for e in entries if e.get("frame_check") and not e["frame_check"]["ok"]]
+        if bad:
+            head["frame_check_failed"] = bad
+            status = 3
+        print(json.dumps(head), flush=True)
+    if env.world > 1:
+        flag = env.torch.tensor([status], dtype=env.torch.int32, device=f"cuda:{env.local_rank}")
+        env.dist.broadcast(flag, src=0)
+        status = int(flag.item())
+        env.dist.barrier()
+        env.dist.destroy_process_group()
+    sys.exit(status)
 
 
 if __name__ == "__main__":

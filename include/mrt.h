@@ -146,8 +146,12 @@ const char *mrt_status_string(int status);
  * tile's lights (scenes with many lights).  Identical buffers in every mode.
  * MRT_OPT_FAIL_NEXT_UPLOAD (test hook; value 1) makes the next mrt_scene_upload of the context fail at its
  * device allocation, after the old scene has been given up: the context must then report MRT_ERR_NO_SCENE.
+ * MRT_OPT_VIEW_CACHE (no reference counterpart; default 1): the small-scene kernel's launcher remembers the last view
+ * (camera + frame size) and, when the same view is rendered again, starts the launch at the tile row where the
+ * geometry begins (a scheduling choice: identical buffers).  0 = every render is treated as the first of its view,
+ * which is what a camera that moves every frame gets anyway (bench.py reports that time as first_view_ms).
  */
-enum { MRT_OPT_CULL = 1, MRT_OPT_RNG_SEED = 2, MRT_OPT_FAIL_NEXT_UPLOAD = 3, MRT_OPT_CULL_TEAM = 4 };
+enum { MRT_OPT_CULL = 1, MRT_OPT_RNG_SEED = 2, MRT_OPT_FAIL_NEXT_UPLOAD = 3, MRT_OPT_CULL_TEAM = 4, MRT_OPT_VIEW_CACHE = 5 };
 int mrt_ctx_set_option(mrt_ctx *ctx, int option, int value);
 
 /*
@@ -225,6 +229,17 @@ int mrt_render_device_static(mrt_ctx *ctx, const mrt_camera *cam, const mrt_rend
 int mrt_scatter_strips(mrt_ctx *ctx, const void *staging_dev, void *frame_rgb_dev, void *frame_id_dev,
                        void *frame_t_dev, int32_t width, int32_t height, int32_t num_ranks, int32_t strip_rows,
                        int32_t skip_rank, void *stream);
+/*
+ * The same when only some planes travel (no reference counterpart).  `planes` = MRT_PLANE_RGB, optionally
+ * | MRT_PLANE_ID | MRT_PLANE_T: a packed buffer then holds rgb [rows_r*W*3], then id [rows_r*W] if gathered, then
+ * t [rows_r*W] if gathered, and the other ranks render only those (NULL id / t pointers to mrt_render_device) --
+ * a caller who wants the picture alone moves 12 bytes per pixel instead of 20.  A plane that does not travel is
+ * left as it is in the frame buffers.  mrt_scatter_strips == planes MRT_PLANES_ALL.
+ */
+enum { MRT_PLANE_RGB = 1, MRT_PLANE_ID = 2, MRT_PLANE_T = 4, MRT_PLANES_ALL = 7 };
+int mrt_scatter_strips_planes(mrt_ctx *ctx, const void *staging_dev, void *frame_rgb_dev, void *frame_id_dev,
+                              void *frame_t_dev, int32_t width, int32_t height, int32_t num_ranks, int32_t strip_rows,
+                              int32_t skip_rank, int32_t planes, void *stream);
 
 /*
  * --- multi-GPU frames over RCCL, behind the C-ABI (no reference counterpart: the reference is single GPU and has
@@ -233,7 +248,10 @@ int mrt_scatter_strips(mrt_ctx *ctx, const void *staging_dev, void *frame_rgb_de
  *   one process per GPU   mrt_comm_unique_id on rank 0, the 128 bytes handed to every rank by whatever the caller
  *                         has (a file, a socket, MPI, torch.distributed), then mrt_comm_create on every rank;
  *   one process, N GPUs   mrt_comm_create_local over N contexts (ncclCommInitAll); mrt_render_multi does the rest.
- * A communicator belongs to the context it was created with.  mrt_comm_destroy(NULL) is a no-op.
+ * A communicator belongs to the context it was created with.  mrt_comm_destroy(NULL) is a no-op.  Destroy order:
+ * either may go first -- mrt_comm_destroy never touches the context (it keeps the GPU ordinal itself), and
+ * mrt_ctx_destroy does not touch communicators; a communicator whose context is gone can only be destroyed.  Every
+ * rank destroys its communicator once its last mrt_gather_strips has completed on the GPU (ncclCommDestroy waits).
  */
 typedef struct mrt_comm mrt_comm;
 enum { MRT_COMM_ID_BYTES = 128 };
@@ -262,6 +280,11 @@ int mrt_comm_destroy(mrt_comm *comm);
 int mrt_gather_strips(mrt_ctx *ctx, mrt_comm *comm, const void *packed_dev, void *staging_dev, void *frame_rgb_dev,
                       void *frame_id_dev, void *frame_t_dev, int32_t width, int32_t height, int32_t strip_rows,
                       int32_t root_in_place, void *stream);
+/* the same with only `planes` travelling (mrt_scatter_strips_planes has the buffer layout): every rank passes the
+ * same mask; staging_dev then holds 3 + [id] + [t] dwords per pixel of every rank that sends */
+int mrt_gather_strips_planes(mrt_ctx *ctx, mrt_comm *comm, const void *packed_dev, void *staging_dev,
+                             void *frame_rgb_dev, void *frame_id_dev, void *frame_t_dev, int32_t width, int32_t height,
+                             int32_t strip_rows, int32_t root_in_place, int32_t planes, void *stream);
 
 /*
  * One process, n GPUs, blocking, HOST buffers: the multi-GPU form of mrt_render.  ctxs[i] renders the strips of rank

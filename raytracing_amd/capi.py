@@ -16,12 +16,13 @@ LIBHOST_PATH = os.path.join(LIB_DIR, "libmrt_host.so")
 GEOM_SPHERE, GEOM_PLANE, GEOM_TRIANGLE = 0, 1, 2
 MAT_DIFFUSE, MAT_METALLIC = 0, 1
 LIGHT_DIRECTIONAL, LIGHT_POINT = 0, 1
+PLANE_RGB, PLANE_ID, PLANE_T, PLANES_ALL = 1, 2, 4, 7
 
 # every symbol include/mrt.h declares (tests check the library exports all of them)
 MRT_SYMBOLS = [
     "mrt_device_count", "mrt_ctx_create", "mrt_ctx_destroy", "mrt_ctx_set_option", "mrt_last_error", "mrt_status_string",
     "mrt_triangle_bound", "mrt_rng_state", "mrt_host_alloc", "mrt_host_free", "mrt_scene_upload", "mrt_local_rows", "mrt_render", "mrt_render_device", "mrt_render_device_static", "mrt_scatter_strips",
-    "mrt_intersect", "mrt_comm_unique_id", "mrt_comm_create", "mrt_comm_create_local", "mrt_comm_destroy",
+    "mrt_scatter_strips_planes", "mrt_gather_strips_planes", "mrt_intersect", "mrt_comm_unique_id", "mrt_comm_create", "mrt_comm_create_local", "mrt_comm_destroy",
     "mrt_gather_strips", "mrt_render_multi",
 ]
 
@@ -112,6 +113,9 @@ def libmrt():
         L.mrt_render_device_static.argtypes = L.mrt_render_device.argtypes
         L.mrt_scatter_strips.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,
                                          C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]
+        L.mrt_scatter_strips_planes.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,
+                                                C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]
+        L.mrt_gather_strips_planes.argtypes = [C.c_void_p] * 7 + [C.c_int32] * 5 + [C.c_void_p]
         L.mrt_intersect.argtypes = [C.c_void_p, C.c_int, _f, _f, C.c_float, C.c_float, C.c_int64, _u8, _f, _f, _f]
         L.mrt_comm_unique_id.argtypes = [C.c_void_p]
         L.mrt_comm_create.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.POINTER(C.c_void_p)]
@@ -397,6 +401,10 @@ class Context:
         of four dealing leaf clusters, 5 teams of four dealing lights.  Identical outputs."""
         self._check(self._L.mrt_ctx_set_option(self._h, 4, int(mode)), "mrt_ctx_set_option")
 
+    def set_view_cache(self, on):
+        """MRT_OPT_VIEW_CACHE: False = the small-scene launcher treats every render as the first of its view."""
+        self._check(self._L.mrt_ctx_set_option(self._h, 5, 1 if on else 0), "mrt_ctx_set_option")
+
     def set_rng_seed(self, seed):
         """Seed of the per-pixel random streams of diffuse bounces (default 1984, as the reference)."""
         self._check(self._L.mrt_ctx_set_option(self._h, 2, int(seed)), "mrt_ctx_set_option")
@@ -457,21 +465,31 @@ class Context:
         self._check(rc, "mrt_render_device_static" if static else "mrt_render_device")
 
     def scatter_strips(self, staging_ptr, rgb_ptr, id_ptr, t_ptr, W, H, num_ranks, strip_rows=8, skip_rank=0,
-                       stream=None):
+                       stream=None, planes=None):
         """Rank 0 after the gather: the packed buffers of the ranks other than skip_rank (in rank order at
-        staging_ptr) go to their strips' places in the three frame planes."""
-        rc = self._L.mrt_scatter_strips(self._h, C.c_void_p(staging_ptr), C.c_void_p(rgb_ptr),
-                                        C.c_void_p(id_ptr) if id_ptr else None, C.c_void_p(t_ptr) if t_ptr else None,
-                                        W, H, num_ranks, strip_rows, skip_rank, C.c_void_p(stream) if stream else None)
+        staging_ptr) go to their strips' places in the three frame planes.  planes: PLANE_* mask of what the packed
+        buffers hold (None: all three, through the older entry point)."""
+        v = lambda p: C.c_void_p(p) if p else None
+        if planes is None:
+            rc = self._L.mrt_scatter_strips(self._h, v(staging_ptr), v(rgb_ptr), v(id_ptr), v(t_ptr), W, H, num_ranks,
+                                            strip_rows, skip_rank, v(stream))
+        else:
+            rc = self._L.mrt_scatter_strips_planes(self._h, v(staging_ptr), v(rgb_ptr), v(id_ptr), v(t_ptr), W, H,
+                                                   num_ranks, strip_rows, skip_rank, int(planes), v(stream))
         self._check(rc, "mrt_scatter_strips")
 
     def gather_strips(self, comm, packed_ptr, staging_ptr, rgb_ptr, id_ptr, t_ptr, W, H, strip_rows=8, root_in_place=True,
-                      stream=None):
+                      stream=None, planes=None):
         """The exchange step of a multi-GPU frame over RCCL (mrt_gather_strips): ranks other than 0 send their packed
         buffer, rank 0 receives them all and puts the strips in place.  Asynchronous on `stream`."""
         v = lambda p: C.c_void_p(p) if p else None
-        rc = self._L.mrt_gather_strips(self._h, comm._h, v(packed_ptr), v(staging_ptr), v(rgb_ptr), v(id_ptr), v(t_ptr),
-                                       W, H, strip_rows, 1 if root_in_place else 0, v(stream))
+        if planes is None:
+            rc = self._L.mrt_gather_strips(self._h, comm._h, v(packed_ptr), v(staging_ptr), v(rgb_ptr), v(id_ptr),
+                                           v(t_ptr), W, H, strip_rows, 1 if root_in_place else 0, v(stream))
+        else:
+            rc = self._L.mrt_gather_strips_planes(self._h, comm._h, v(packed_ptr), v(staging_ptr), v(rgb_ptr), v(id_ptr),
+                                                  v(t_ptr), W, H, strip_rows, 1 if root_in_place else 0, int(planes),
+                                                  v(stream))
         self._check(rc, "mrt_gather_strips")
 
     def intersect(self, prim_kind, prim, rays, tmin, tmax):
@@ -521,7 +539,7 @@ class Comm:
             pass
 
 
-def render_multi(ctxs, cam12, W, H, spp=1, max_depth=0, strip_rows=8, comms=None, want_stats=True):
+def render_multi(ctxs, cam12, W, H, spp=1, max_depth=0, strip_rows=8, comms=None, want_stats=True, planes=PLANES_ALL):
     """One process, len(ctxs) GPUs (mrt_render_multi): blocking render of the whole frame into host arrays.  comms:
     raw handles from mrt_comm_create_local, created here (and destroyed) when None and more than one context."""
     L = libmrt()
@@ -539,8 +557,10 @@ def render_multi(ctxs, cam12, W, H, spp=1, max_depth=0, strip_rows=8, comms=None
     p = Context._params(W, H, spp, max_depth, 0, 1, strip_rows)
     st = Stats()
     try:
-        rc = L.mrt_render_multi(hs, comms, n, C.byref(cam), C.byref(p), rgb.ctypes.data, ids.ctypes.data, t.ctypes.data,
-                                C.byref(st) if want_stats else None)
+        # a plane the caller does not ask for (NULL) is neither rendered by the other ranks nor gathered
+        rc = L.mrt_render_multi(hs, comms, n, C.byref(cam), C.byref(p), rgb.ctypes.data,
+                                ids.ctypes.data if planes & PLANE_ID else None,
+                                t.ctypes.data if planes & PLANE_T else None, C.byref(st) if want_stats else None)
         ctxs[0]._check(rc, "mrt_render_multi")
     finally:
         if own is not None:

@@ -52,6 +52,7 @@ struct mrt_ctx {
   std::vector<float> small_tri16, small_sph;
   std::vector<int32_t> small_tri_obj, small_sph_obj;
   mrt::SmallViewCache small_view; // last view of the small-scene launcher (reset by an upload)
+  bool view_cache = true;         // MRT_OPT_VIEW_CACHE
 
   // per-pixel XORWOW streams of the diffuse bounce (mrt_rng.hip): jump matrices, and the xorshift words of
   // streams 0..rng_n-1 for seed rng_seed (5 streams of rng_n words), built on first need
@@ -116,7 +117,15 @@ static thread_local std::string g_create_err;
 
 static int fail(mrt_ctx *ctx, int code, const std::string &msg)
 {
-  if (ctx) ctx->err = msg; else g_create_err = msg;
+  try { if (ctx) ctx->err = msg; else g_create_err = msg; } catch (...) {} // never throws through the C-ABI
+  return code;
+}
+
+// Literal messages go straight into the context's string, whose capacity mrt_ctx_create reserved: no heap on the
+// error paths of the allocation-free entry point either.
+static int fail(mrt_ctx *ctx, int code, const char *msg)
+{
+  try { if (ctx) ctx->err.assign(msg); else g_create_err.assign(msg); } catch (...) {}
   return code;
 }
 
@@ -240,7 +249,7 @@ static hipError_t ensure_rng_states(mrt_ctx *ctx, size_t npix)
 static mrt::SmallHost small_host(mrt_ctx *ctx)
 {
   mrt::SmallHost hs;
-  hs.view = &ctx->small_view;
+  hs.view = ctx->view_cache ? &ctx->small_view : nullptr;
   hs.ns = (int)ctx->small_sph_obj.size(); hs.nt = (int)ctx->small_tri_obj.size();
   hs.sph = ctx->small_sph.data(); hs.sph_obj = ctx->small_sph_obj.data();
   hs.tri16 = ctx->small_tri16.data(); hs.tri_obj = ctx->small_tri_obj.data();
@@ -309,6 +318,12 @@ int mrt_ctx_set_option(mrt_ctx *ctx, int option, int value)
     ctx->fail_next_upload = value != 0;
     return MRT_OK;
   }
+  if (option == MRT_OPT_VIEW_CACHE) {
+    if (value != 0 && value != 1) return fail(ctx, MRT_ERR_INVALID, "MRT_OPT_VIEW_CACHE takes 0 or 1");
+    ctx->view_cache = value != 0;
+    ctx->small_view = mrt::SmallViewCache();
+    return MRT_OK;
+  }
   if (option == MRT_OPT_RNG_SEED) {
     if (value < 0) return fail(ctx, MRT_ERR_INVALID, "MRT_OPT_RNG_SEED takes 0..2^31-1");
     ctx->rng_seed = (uint64_t)value;
@@ -354,6 +369,7 @@ int mrt_ctx_create(int device, mrt_ctx **out)
   if (!ctx) return fail(nullptr, MRT_ERR_INVALID, "out of host memory");
   ctx->device = device;
   ctx->cull = use_cull();
+  try { ctx->err.reserve(512); } catch (...) { delete ctx; return fail(nullptr, MRT_ERR_INVALID, "out of host memory"); }
   auto bail = [&](hipError_t err, const char *what) {
     int rc = hip_fail(nullptr, err, what);
     mrt_ctx_destroy(ctx);
@@ -739,10 +755,22 @@ int mrt_render(mrt_ctx *ctx, const mrt_camera *cam, const mrt_render_params *par
   return MRT_OK;
 }
 
+static bool planes_ok(int32_t planes) { return (planes & MRT_PLANE_RGB) && (planes & ~MRT_PLANES_ALL) == 0; }
+static int plane_dwords(int32_t planes) { return 3 + ((planes & MRT_PLANE_ID) ? 1 : 0) + ((planes & MRT_PLANE_T) ? 1 : 0); }
+
 int mrt_scatter_strips(mrt_ctx *ctx, const void *staging_dev, void *frame_rgb_dev, void *frame_id_dev, void *frame_t_dev,
                        int32_t width, int32_t height, int32_t num_ranks, int32_t strip_rows, int32_t skip_rank, void *stream)
 {
+  return mrt_scatter_strips_planes(ctx, staging_dev, frame_rgb_dev, frame_id_dev, frame_t_dev, width, height, num_ranks,
+                                   strip_rows, skip_rank, MRT_PLANES_ALL, stream);
+}
+
+int mrt_scatter_strips_planes(mrt_ctx *ctx, const void *staging_dev, void *frame_rgb_dev, void *frame_id_dev,
+                              void *frame_t_dev, int32_t width, int32_t height, int32_t num_ranks, int32_t strip_rows,
+                              int32_t skip_rank, int32_t planes, void *stream)
+{
   if (!ctx) return MRT_ERR_INVALID;
+  if (!planes_ok(planes)) return fail(ctx, MRT_ERR_INVALID, "planes: MRT_PLANE_RGB, optionally | MRT_PLANE_ID | MRT_PLANE_T");
   if (!staging_dev || !frame_rgb_dev) return fail(ctx, MRT_ERR_INVALID, "staging and rgb frame buffers are required");
   if (width <= 0 || height <= 0) return fail(ctx, MRT_ERR_INVALID, "non-positive frame size");
   if (num_ranks > mrt::MAX_RANKS) return fail(ctx, MRT_ERR_TOO_LARGE, "more than 64 ranks");
@@ -754,12 +782,13 @@ int mrt_scatter_strips(mrt_ctx *ctx, const void *staging_dev, void *frame_rgb_de
   S.staging = (const uint32_t *)staging_dev;
   S.rgb = (uint32_t *)frame_rgb_dev; S.id = (uint32_t *)frame_id_dev; S.t = (uint32_t *)frame_t_dev;
   S.W = width; S.H = height; S.nranks = num_ranks; S.strip_rows = strip_rows; S.skip_rank = skip_rank;
+  S.has_id = (planes & MRT_PLANE_ID) ? 1 : 0; S.has_t = (planes & MRT_PLANE_T) ? 1 : 0;
   uint64_t off = 0;
   for (int r = 0; r < num_ranks; ++r) {
     p.rank = r;
     S.rank_rows[r] = local_rows_of(height, p);
     S.rank_off[r] = off;
-    if (r != skip_rank) off += (uint64_t)S.rank_rows[r] * (uint64_t)width * 5;
+    if (r != skip_rank) off += (uint64_t)S.rank_rows[r] * (uint64_t)width * (uint64_t)plane_dwords(planes);
   }
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   HIP_TRY(ctx, mrt::launch_scatter(S, (hipStream_t)stream));
@@ -873,7 +902,8 @@ int rccl_fail(mrt_ctx *ctx, const Rccl *R, ncclResult_t r, const char *what)
 
 struct mrt_comm {
   ncclComm_t comm = nullptr;
-  mrt_ctx *ctx = nullptr;
+  mrt_ctx *ctx = nullptr; // identity check in mrt_gather_strips only after creation; never dereferenced by destroy
+  int device = 0;         // the context's GPU, kept here so that mrt_comm_destroy works whichever is destroyed first
   int rank = 0, nranks = 1;
 };
 
@@ -884,14 +914,15 @@ struct mrt_comm {
   } while (0)
 
 // dword offset of every rank's packed buffer in rank 0's staging area, and its length; `skip` sends nothing
-static uint64_t staging_layout(int W, int H, int nranks, int strip_rows, int skip, uint64_t *off, uint64_t *len)
+static uint64_t staging_layout(int W, int H, int nranks, int strip_rows, int skip, int dwords_per_pixel, uint64_t *off,
+                               uint64_t *len)
 {
   uint64_t o = 0;
   mrt_partition p{0, nranks, strip_rows, 0};
   for (int r = 0; r < nranks; ++r) {
     p.rank = r;
     off[r] = o;
-    len[r] = r == skip ? 0 : (uint64_t)local_rows_of(H, p) * (uint64_t)W * 5;
+    len[r] = r == skip ? 0 : (uint64_t)local_rows_of(H, p) * (uint64_t)W * (uint64_t)dwords_per_pixel;
     o += len[r];
   }
   return o;
@@ -923,7 +954,7 @@ int mrt_comm_create(mrt_ctx *ctx, const uint8_t id[MRT_COMM_ID_BYTES], int32_t r
   if (!R) return fail(ctx, MRT_ERR_HIP, why);
   mrt_comm *c = new (std::nothrow) mrt_comm();
   if (!c) return fail(ctx, MRT_ERR_INVALID, "out of host memory");
-  c->ctx = ctx; c->rank = rank; c->nranks = num_ranks;
+  c->ctx = ctx; c->device = ctx->device; c->rank = rank; c->nranks = num_ranks;
   ncclUniqueId u;
   std::memcpy(&u, id, sizeof u);
   hipError_t e = hipSetDevice(ctx->device);
@@ -955,7 +986,7 @@ int mrt_comm_create_local(mrt_ctx *const *ctxs, int32_t n, mrt_comm **out)
       for (int j = 0; j < n; ++j) { (void)R->CommDestroy(comms[j]); delete out[j]; out[j] = nullptr; }
       return fail(c0, MRT_ERR_INVALID, "out of host memory");
     }
-    c->comm = comms[i]; c->ctx = ctxs[i]; c->rank = i; c->nranks = n;
+    c->comm = comms[i]; c->ctx = ctxs[i]; c->device = ctxs[i]->device; c->rank = i; c->nranks = n;
     out[i] = c;
   }
   return MRT_OK;
@@ -967,9 +998,11 @@ int mrt_comm_destroy(mrt_comm *comm)
   const Rccl *R = rccl(nullptr);
   int rc = MRT_OK;
   if (R && comm->comm) {
-    if (comm->ctx) (void)hipSetDevice(comm->ctx->device);
+    (void)hipSetDevice(comm->device);
     ncclResult_t r = R->CommDestroy(comm->comm);
-    if (r != ncclSuccess) rc = rccl_fail(comm->ctx, R, r, "ncclCommDestroy");
+    // the context may be gone already (either destroy order is allowed, include/mrt.h): the message goes to the
+    // thread's creation-error slot, which mrt_last_error(NULL) reads
+    if (r != ncclSuccess) rc = rccl_fail(nullptr, R, r, "ncclCommDestroy");
   }
   delete comm;
   return rc;
@@ -978,9 +1011,10 @@ int mrt_comm_destroy(mrt_comm *comm)
 // scatter = false: the caller has a group open (the receives are only enqueued when it closes) and scatters itself
 static int gather_strips(mrt_ctx *ctx, mrt_comm *comm, const void *packed_dev, void *staging_dev, void *frame_rgb_dev,
                          void *frame_id_dev, void *frame_t_dev, int32_t width, int32_t height, int32_t strip_rows,
-                         int32_t root_in_place, void *stream, bool scatter)
+                         int32_t root_in_place, int32_t planes, void *stream, bool scatter)
 {
   if (!ctx || !comm) return MRT_ERR_INVALID;
+  if (!planes_ok(planes)) return fail(ctx, MRT_ERR_INVALID, "planes: MRT_PLANE_RGB, optionally | MRT_PLANE_ID | MRT_PLANE_T");
   if (comm->ctx != ctx) return fail(ctx, MRT_ERR_INVALID, "mrt_gather_strips: the communicator belongs to another context");
   if (width <= 0 || height <= 0) return fail(ctx, MRT_ERR_INVALID, "non-positive frame size");
   const int N = comm->nranks, me = comm->rank;
@@ -990,7 +1024,7 @@ static int gather_strips(mrt_ctx *ctx, mrt_comm *comm, const void *packed_dev, v
   if (!R) return fail(ctx, MRT_ERR_HIP, "RCCL is not open");
   const int skip = root_in_place ? 0 : -1;
   uint64_t off[mrt::MAX_RANKS], len[mrt::MAX_RANKS];
-  staging_layout(width, height, N, strip_rows, skip, off, len);
+  staging_layout(width, height, N, strip_rows, skip, plane_dwords(planes), off, len);
   hipStream_t st = (hipStream_t)stream;
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   if (me != 0) {
@@ -1015,7 +1049,8 @@ static int gather_strips(mrt_ctx *ctx, mrt_comm *comm, const void *packed_dev, v
   if (r1 != ncclSuccess) return rccl_fail(ctx, R, r1, "ncclSend / ncclRecv");
   if (r2 != ncclSuccess) return rccl_fail(ctx, R, r2, "ncclGroupEnd");
   if (!scatter) return MRT_OK;
-  return mrt_scatter_strips(ctx, staging_dev, frame_rgb_dev, frame_id_dev, frame_t_dev, width, height, N, strip_rows, skip, stream);
+  return mrt_scatter_strips_planes(ctx, staging_dev, frame_rgb_dev, frame_id_dev, frame_t_dev, width, height, N, strip_rows, skip,
+                                   planes, stream);
 }
 
 int mrt_gather_strips(mrt_ctx *ctx, mrt_comm *comm, const void *packed_dev, void *staging_dev, void *frame_rgb_dev,
@@ -1023,7 +1058,15 @@ int mrt_gather_strips(mrt_ctx *ctx, mrt_comm *comm, const void *packed_dev, void
                       int32_t root_in_place, void *stream)
 {
   return gather_strips(ctx, comm, packed_dev, staging_dev, frame_rgb_dev, frame_id_dev, frame_t_dev, width, height,
-                       strip_rows, root_in_place, stream, true);
+                       strip_rows, root_in_place, MRT_PLANES_ALL, stream, true);
+}
+
+int mrt_gather_strips_planes(mrt_ctx *ctx, mrt_comm *comm, const void *packed_dev, void *staging_dev, void *frame_rgb_dev,
+                             void *frame_id_dev, void *frame_t_dev, int32_t width, int32_t height, int32_t strip_rows,
+                             int32_t root_in_place, int32_t planes, void *stream)
+{
+  return gather_strips(ctx, comm, packed_dev, staging_dev, frame_rgb_dev, frame_id_dev, frame_t_dev, width, height,
+                       strip_rows, root_in_place, planes, stream, true);
 }
 
 int mrt_render_multi(mrt_ctx *const *ctxs, mrt_comm *const *comms, int32_t n, const mrt_camera *cam,
@@ -1048,13 +1091,16 @@ int mrt_render_multi(mrt_ctx *const *ctxs, mrt_comm *const *comms, int32_t n, co
     int rc = fill_args(ctxs[r], cam, &p, A[r]);
     if (rc != MRT_OK) { if (r) fail(c0, rc, ctxs[r]->err); return rc; }
   }
-  const uint64_t staging_dwords = staging_layout(W, H, n, strip_rows, 0, off, len);
+  // only the planes the caller asked for are rendered by the other ranks and travel (rgb alone: 12 of 20 bytes a pixel)
+  const int32_t planes = MRT_PLANE_RGB | (id ? MRT_PLANE_ID : 0) | (t ? MRT_PLANE_T : 0);
+  const int pd = plane_dwords(planes);
+  const uint64_t staging_dwords = staging_layout(W, H, n, strip_rows, 0, pd, off, len);
   const size_t npix = (size_t)W * H;
   for (int r = 0; r < n; ++r) {
     mrt_ctx *ctx = ctxs[r];
     const size_t lpix = (size_t)A[r].local_rows * W;
     // rank 0: the frame planes, then the staging area; other ranks: their packed rgb | id | t planes
-    const size_t need = (r == 0 ? (npix * 5 + (size_t)staging_dwords) : lpix * 5) * 4 + 256;
+    const size_t need = (r == 0 ? (npix * 5 + (size_t)staging_dwords) : lpix * (size_t)pd) * 4 + 256;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     if (ctx->out_bytes < need) {
       HIP_TRY(ctx, drain(ctx));
@@ -1062,10 +1108,15 @@ int mrt_render_multi(mrt_ctx *const *ctxs, mrt_comm *const *comms, int32_t n, co
       HIP_TRY(ctx, hipMalloc(&ctx->out_mem, need));
       ctx->out_bytes = need;
     }
-    const size_t planes = r == 0 ? npix : lpix;
+    const size_t ppix = r == 0 ? npix : lpix;
     A[r].rgb = (float *)ctx->out_mem;
-    A[r].id = (int32_t *)((char *)ctx->out_mem + planes * 12);
-    A[r].t = (float *)((char *)ctx->out_mem + planes * 16);
+    if (r == 0) { // the frame planes: all three have their place, whatever travels
+      A[r].id = id ? (int32_t *)((char *)ctx->out_mem + ppix * 12) : nullptr;
+      A[r].t = t ? (float *)((char *)ctx->out_mem + ppix * 16) : nullptr;
+    } else {      // the packed buffer: rgb | id (if gathered) | t (if gathered)
+      A[r].id = id ? (int32_t *)((char *)ctx->out_mem + ppix * 12) : nullptr;
+      A[r].t = t ? (float *)((char *)ctx->out_mem + ppix * (id ? 16 : 12)) : nullptr;
+    }
     A[r].stats = stats ? ctx->stats_dev : nullptr;
     A[r].stats_slots = STATS_SLOTS;
     HIP_TRY(ctx, order_after_last(ctx, ctx->stream));
@@ -1086,14 +1137,15 @@ int mrt_render_multi(mrt_ctx *const *ctxs, mrt_comm *const *comms, int32_t n, co
       mrt_ctx *ctx = ctxs[r];
       void *staging = r == 0 ? (char *)ctx->out_mem + npix * 20 : nullptr;
       rc1 = gather_strips(ctx, comms[r], r == 0 ? nullptr : ctx->out_mem, staging, r == 0 ? A[0].rgb : nullptr,
-                          r == 0 ? A[0].id : nullptr, r == 0 ? A[0].t : nullptr, W, H, strip_rows, 1, ctx->stream, false);
+                          r == 0 ? A[0].id : nullptr, r == 0 ? A[0].t : nullptr, W, H, strip_rows, 1, planes, ctx->stream, false);
       if (rc1 != MRT_OK && r) fail(c0, rc1, ctx->err);
     }
     ncclResult_t r2 = R->GroupEnd();
     if (rc1 != MRT_OK) return rc1;
     if (r2 != ncclSuccess) return rccl_fail(c0, R, r2, "ncclGroupEnd");
     if (staging_dwords) {
-      rc1 = mrt_scatter_strips(c0, (char *)c0->out_mem + npix * 20, A[0].rgb, A[0].id, A[0].t, W, H, n, strip_rows, 0, c0->stream);
+      rc1 = mrt_scatter_strips_planes(c0, (char *)c0->out_mem + npix * 20, A[0].rgb, A[0].id, A[0].t, W, H, n, strip_rows, 0,
+                                      planes, c0->stream);
       if (rc1 != MRT_OK) return rc1;
     }
   }

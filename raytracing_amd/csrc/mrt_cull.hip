@@ -65,7 +65,7 @@ template <> struct CVec<4> { typedef float f __attribute__((ext_vector_type(4)))
 // exact tests per light and tile in the 64-light config) and what a tile costs is the per-light set-up, 64 times:
 // dealing leaves would repeat that set-up in every member.  The reference adds the lights' contributions to a pixel
 // in light order (core/light.cuh:171-173; fp32 addition does not associate), so a member does not add up its own
-// lights: it leaves each light's contribution in LDS, and member 0 folds them in order, 32 lights at a time.
+// lights: it leaves each light's contribution in LDS, and member 0 folds them in order, LCH = 16 lights at a time.
 #ifndef MRT_REFINE_MD
 #define MRT_REFINE_MD 1
 #endif
@@ -115,6 +115,7 @@ void render_cull_kernel(RenderArgs A)
   const int tile_y = blockIdx.y;
   if (tile_x * TW >= A.W) return; // NW == 1: waves are independent; NW > 1: the whole team leaves
   int leaf_k = 0; // leaf clusters met so far in the current walk (the same sequence in every member)
+  [[maybe_unused]] int open_set = 0; // which set of tm_open the next merged light uses (the same in every member)
 #define MRT_TEAM_TAKES_LEAF() (NW == 1 || (leaf_k++ % NWS) == member)
 #define MRT_TEAM_TAKES_SHADOW_LEAF() (NW == 1 || LSPLIT || (leaf_k++ % NWS) == member)
 #ifdef MRT_TIMELINE
@@ -625,15 +626,19 @@ void render_cull_kernel(RenderArgs A)
 
         if constexpr (NW > 1 && !LSPLIT) {
           if (team_need) {
-            // a shadow ray is free only if no member found an occluder: AND of the members' masks (slots alternate
-            // between lights, so one barrier per light is enough)
+            // a shadow ray is free only if no member found an occluder: AND of the members' masks.  The two sets of
+            // slots alternate between the lights that GET HERE (team_need is the same in every member), so one barrier
+            // per such light is enough: whoever writes a set again has passed the barrier of the light in between,
+            // which every reader of the set reaches only after its reads.  (Alternating by the light's number would
+            // let a light that skips the barrier put two users of one set back to back.)
             const unsigned long long mine = __ballot(open[0]);
-            if (lane == 0) tm_open[(li & 1) * NWS + member] = mine;
+            if (lane == 0) tm_open[open_set * NWS + member] = mine;
             __syncthreads();
             unsigned long long all = ~0ull;
 #pragma unroll
-            for (int w = 0; w < NWS; ++w) all &= tm_open[(li & 1) * NWS + w];
+            for (int w = 0; w < NWS; ++w) all &= tm_open[open_set * NWS + w];
             open[0] = (all >> lane) & 1ull;
+            open_set ^= 1;
           }
           if (member != 0) return; // member 0 shades
         }

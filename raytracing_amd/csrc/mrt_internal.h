@@ -172,6 +172,7 @@ struct ScatterArgs {
   const uint32_t *staging;
   uint32_t *rgb, *id, *t;          // frame planes (id / t may be null)
   int32_t W, H, nranks, strip_rows, skip_rank;
+  int32_t has_id, has_t;           // which planes follow rgb in a packed buffer (MRT_PLANE_ID / MRT_PLANE_T)
   int32_t rank_rows[MAX_RANKS];    // rows of rank r
   uint64_t rank_off[MAX_RANKS];    // dword offset of rank r's packed buffer in staging
 };

@@ -743,8 +743,9 @@ __global__ __launch_bounds__(256) void scatter_kernel(ScatterArgs S)
   const size_t W = size_t(S.W), rr = size_t(S.rank_rows[r]);
   const uint32_t *base = S.staging + S.rank_off[r];
   copy_block(base + lrow0 * W * 3, S.rgb + size_t(row0) * W * 3, size_t(rows) * W * 3);
-  if (S.id) copy_block(base + rr * W * 3 + lrow0 * W, S.id + size_t(row0) * W, size_t(rows) * W);
-  if (S.t) copy_block(base + rr * W * 4 + lrow0 * W, S.t + size_t(row0) * W, size_t(rows) * W);
+  // the planes a packed buffer holds follow each other: rgb | id (if gathered) | t (if gathered)
+  if (S.id && S.has_id) copy_block(base + rr * W * 3 + lrow0 * W, S.id + size_t(row0) * W, size_t(rows) * W);
+  if (S.t && S.has_t) copy_block(base + rr * W * (S.has_id ? 4 : 3) + lrow0 * W, S.t + size_t(row0) * W, size_t(rows) * W);
 }
 
 hipError_t launch_scatter(const ScatterArgs &S, hipStream_t stream)

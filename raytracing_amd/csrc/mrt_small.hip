@@ -879,12 +879,12 @@ static int small_first_row(const SmallArgs &S, int ns, int nt, int P, int lx, in
 {
   const int TW = lx * P, LY = 64 / lx;
   const float rw = 1.0f / float(S.A.W), rh = 1.0f / float(S.A.H);
-  std::vector<int> cand((size_t)tiles_y, 0);
-  long total = 0;
   // a bounded amount of host work whatever the frame: every xs-th column of tiles (the rule below only compares counts)
   const long work = (long)tiles_x * tiles_y * (ns + nt > 0 ? ns + nt : 1);
   const int xs = int(work / 2000000L) + 1;
-  for (int y = 0; y < tiles_y; ++y) {
+  // candidate tiles of one row.  No heap here: this runs inside mrt_render_device_static, which promises to call no
+  // allocating routine (include/mrt.h) -- the rows are counted twice (total, then cumulative) instead of being kept.
+  auto row_candidates = [&](int y) {
     const float vm = (float(y * LY) + 0.5f * float(LY - 1)) * rh;
     int c = 0;
     for (int x = 0; x < tiles_x; x += xs) {
@@ -900,14 +900,15 @@ static int small_first_row(const SmallArgs &S, int ns, int nt, int P, int lx, in
       }
       c += any ? 1 : 0;
     }
-    cand[(size_t)y] = c;
-    total += c;
-  }
+    return c;
+  };
+  long total = 0;
+  for (int y = 0; y < tiles_y; ++y) total += row_candidates(y);
   if (total == 0) return 0;
   long cum = 0;
   int first = 0;
   for (; first < tiles_y; ++first) {
-    cum += cand[(size_t)first];
+    cum += row_candidates(first);
     if (cum * 50 > total) break; // more than 2 % of the candidate tiles lie in rows 0..first
   }
   const int margin = tiles_y / 20 > 2 ? tiles_y / 20 : 2;

@@ -2,8 +2,8 @@
 
 The scene is replicated; the frame is dealt to ranks in strips of rows (strip s -> rank s % N, include/mrt.h
 mrt_partition).  Rank 0 renders its own strips straight into the final frame (frame_layout 1); every other rank
-renders its strips back to back into ONE packed buffer -- rgb | id | t planes of its rows -- and sends that buffer
-to rank 0: one message per peer, each over the peer's own xGMI link, all of them received in one group.  Rank 0 then
+renders its strips back to back into ONE packed buffer -- rgb | id | t planes of its rows (or only those of them the caller wants gathered) -- and sends that
+buffer to rank 0: one message per peer, each over the peer's own xGMI link, all of them received in one group.  Rank 0 then
 copies the peers' strips from the staging area to their places in the three frame planes (mrt_scatter_strips: one
 pass over the (N-1)/N of the frame that came from elsewhere; its own rows are never copied).  There is no other
 exchange step and no reference counterpart: the reference is single-GPU.
@@ -17,7 +17,12 @@ import numpy as np
 
 from . import capi
 
-PLANE_DWORDS = 5  # per pixel: rgb 3 x f32, id i32, t f32
+PLANE_DWORDS = 5  # per pixel with every plane: rgb 3 x f32, id i32, t f32
+
+
+def plane_dwords(planes=capi.PLANES_ALL):
+    """4-byte elements per pixel of a packed buffer that holds `planes` (capi.PLANE_* mask; rgb always)."""
+    return 3 + (1 if planes & capi.PLANE_ID else 0) + (1 if planes & capi.PLANE_T else 0)
 
 
 def rank_rows(height, num_ranks, strip_rows=8):
@@ -33,12 +38,12 @@ def default_strip_rows(height, num_ranks):
     return max(8, (height // (num_ranks * 6)) // 8 * 8)
 
 
-def staging_offsets(height, width, num_ranks, strip_rows=8, skip_rank=0):
+def staging_offsets(height, width, num_ranks, strip_rows=8, skip_rank=0, planes=capi.PLANES_ALL):
     """(offset, length) in 4-byte elements of every rank's packed buffer in rank 0's staging area (the layout
     mrt_scatter_strips reads); skip_rank has length 0."""
     out, off = [], 0
     for r, rows in enumerate(rank_rows(height, num_ranks, strip_rows)):
-        n = 0 if r == skip_rank else rows * width * PLANE_DWORDS
+        n = 0 if r == skip_rank else rows * width * plane_dwords(planes)
         out.append((off, n))
         off += n
     return out, off
@@ -70,31 +75,44 @@ def exchange_packed(packed, staging, offsets, rank, num_ranks, dst=0, group=None
                 w.wait()
 
 
-def scatter_strips_host(staging, offsets, rgb, ids, tt, num_ranks, strip_rows=8, skip_rank=0):
-    """numpy mirror of mrt_scatter_strips (CPU tests of the N > 1 path): staging is a flat float32 array, the
-    frame planes are [H, W, 3] float32, [H, W] int32, [H, W] float32."""
-    H, W = ids.shape
+def scatter_strips_host(staging, offsets, rgb, ids, tt, num_ranks, strip_rows=8, skip_rank=0, planes=capi.PLANES_ALL):
+    """numpy mirror of mrt_scatter_strips(_planes) (CPU tests of the N > 1 path): staging is a flat float32 array, the
+    frame planes are [H, W, 3] float32, [H, W] int32, [H, W] float32; a plane that does not travel is left alone."""
+    H, W = rgb.shape[:2]
     for r in range(num_ranks):
         if r == skip_rank:
             continue
         rows = capi.local_row_index(H, r, num_ranks, strip_rows)
         n, (o, _) = len(rows), offsets[r]
         rgb[rows] = staging[o:o + n * W * 3].reshape(n, W, 3)
-        ids[rows] = staging[o + n * W * 3:o + n * W * 4].view(np.int32).reshape(n, W)
-        tt[rows] = staging[o + n * W * 4:o + n * W * 5].reshape(n, W)
+        o += n * W * 3
+        if planes & capi.PLANE_ID:
+            ids[rows] = staging[o:o + n * W].view(np.int32).reshape(n, W)
+            o += n * W
+        if planes & capi.PLANE_T:
+            tt[rows] = staging[o:o + n * W].reshape(n, W)
 
 
 class FrameRenderer:
-    """Renders frames of one scene on this rank's GPU and, for N > 1, collects them on rank 0."""
+    """Renders frames of one scene on this rank's GPU and, for N > 1, collects them on rank 0.
+
+    planes: what travels to rank 0 and what the ranks render for it -- rgb always, id and t on request (the picture
+    alone is 12 of the 20 bytes per pixel; at N = 1 all three planes are always written).
+    pipeline: frames in flight at N > 1.  1: render, then exchange, on one stream.  2 (default): two sets of buffers;
+    the exchange (+ rank 0's scatter) of frame k runs on a side stream while frame k + 1 renders, with events between
+    the two streams, so a stream of frames costs max(render, exchange) per frame, not the sum.  self.rgb / ids / tt
+    are the planes of the frame the last step() produced (complete once both streams have been synchronised)."""
 
     def __init__(self, flat_scene, cam12, width, height, rank=0, num_ranks=1, device=0, strip_rows=None, spp=1,
-                 max_depth=0):
+                 max_depth=0, planes=capi.PLANES_ALL, pipeline=2):
         import torch
 
         self.torch = torch
         self.rank, self.num_ranks = rank, num_ranks
         self.strip_rows = strip_rows or default_strip_rows(height, num_ranks)
         self.W, self.H, self.spp, self.max_depth = width, height, spp, max_depth
+        self.planes = capi.PLANES_ALL if num_ranks == 1 else (int(planes) | capi.PLANE_RGB)
+        self.depth = 1 if num_ranks == 1 else max(1, min(2, int(pipeline)))
         self.cam12 = np.ascontiguousarray(cam12, dtype=np.float32)
         self.dev = torch.device(f"cuda:{device}")
         torch.cuda.set_device(self.dev)
@@ -102,23 +120,58 @@ class FrameRenderer:
         self.ctx.upload(flat_scene)
         self.local_rows = capi.local_rows(height, rank, num_ranks, self.strip_rows)
         self.stats = torch.zeros(8, dtype=torch.int64, device=self.dev)
-        self.offsets, total = staging_offsets(height, width, num_ranks, self.strip_rows, skip_rank=0)
-        self.packed = self.staging = None
-        if rank == 0:
-            # whole frame; with N > 1 only rank 0's own rows are rendered here, the rest arrives
-            n = height * width
-            self.frame = torch.zeros(n * PLANE_DWORDS, dtype=torch.float32, device=self.dev)
-            self.rgb, self.ids, self.tt = self.frame[:n * 3], self.frame[n * 3:n * 4].view(torch.int32), self.frame[n * 4:]
-            self.layout = 1 if num_ranks > 1 else 0
-            if num_ranks > 1:
-                self.staging = torch.empty(total, dtype=torch.float32, device=self.dev)
-        else:
-            n = self.local_rows * width
-            self.packed = torch.zeros(n * PLANE_DWORDS, dtype=torch.float32, device=self.dev)
-            self.rgb, self.ids, self.tt = self.packed[:n * 3], self.packed[n * 3:n * 4].view(torch.int32), self.packed[n * 4:]
-            self.layout = 0
-        self._call = None
+        self.offsets, total = staging_offsets(height, width, num_ranks, self.strip_rows, skip_rank=0, planes=self.planes)
+        has_id, has_t = bool(self.planes & capi.PLANE_ID), bool(self.planes & capi.PLANE_T)
+        self.slots = []  # per frame in flight: dict(buf, rgb, ids, tt, staging)
+        for _ in range(self.depth):
+            if rank == 0:
+                # whole frame; with N > 1 only rank 0's own rows are rendered here, the rest arrives
+                n = height * width
+                buf = torch.zeros(n * PLANE_DWORDS, dtype=torch.float32, device=self.dev)
+                sl = {"buf": buf, "rgb": buf[:n * 3], "ids": buf[n * 3:n * 4].view(torch.int32), "tt": buf[n * 4:],
+                      "staging": torch.empty(total, dtype=torch.float32, device=self.dev) if num_ranks > 1 else None}
+                if not has_id:
+                    sl["ids"] = None
+                if not has_t:
+                    sl["tt"] = None
+            else:
+                # this rank's rows back to back: rgb | id (if it travels) | t (if it travels)
+                n = self.local_rows * width
+                buf = torch.zeros(n * plane_dwords(self.planes), dtype=torch.float32, device=self.dev)
+                o = n * 3
+                sl = {"buf": buf, "rgb": buf[:o], "ids": None, "tt": None, "staging": None}
+                if has_id:
+                    sl["ids"] = buf[o:o + n].view(torch.int32)
+                    o += n
+                if has_t:
+                    sl["tt"] = buf[o:o + n]
+            self.slots.append(sl)
+        self.layout = 1 if (rank == 0 and num_ranks > 1) else 0
+        self.frames = 0      # frames started
+        self._calls = {}
         self.comm = None
+        self.xstream = None
+        if self.depth > 1:
+            self.xstream = torch.cuda.Stream(device=self.dev)
+            self.ev_rendered = [torch.cuda.Event() for _ in range(self.depth)]
+            self.ev_free = [torch.cuda.Event() for _ in range(self.depth)]
+            self._used = [False] * self.depth
+
+    # the planes of the frame the last step() / render_local() produced
+    def _last(self):
+        return self.slots[(self.frames - 1) % self.depth if self.frames else 0]
+
+    rgb = property(lambda self: self._last()["rgb"])
+    ids = property(lambda self: self._last()["ids"])
+    tt = property(lambda self: self._last()["tt"])
+    packed = property(lambda self: None if self.rank == 0 else self._last()["buf"])
+    staging = property(lambda self: self._last()["staging"])
+
+    def describe(self):
+        """What is switched on, for the bench line."""
+        names = ["rgb"] + (["id"] if self.planes & capi.PLANE_ID else []) + (["t"] if self.planes & capi.PLANE_T else [])
+        return {"pipeline_depth": self.depth, "planes_gathered": "+".join(names),
+                "bytes_per_pixel_gathered": 4 * plane_dwords(self.planes), "weighted_partition": False}
 
     def init_comm(self, unique_id):
         """Collective over the ranks: from now on the exchange step goes through mrt_gather_strips (RCCL behind the
@@ -130,46 +183,69 @@ class FrameRenderer:
             self.comm.close()
             self.comm = None
 
-    def render_local(self, want_stats=False):
-        """Enqueue this rank's strips on torch's current stream (asynchronous)."""
+    def _render_slot(self, s, want_stats=False):
         import ctypes as C
-        if self._call is None:  # argument structs are built once: a frame is tens of microseconds
+        if s not in self._calls:  # argument structs are built once: a frame is tens of microseconds
+            sl = self.slots[s]
             cam = capi.Camera.from12(self.cam12)
             par = capi.Context._params(self.W, self.H, self.spp, self.max_depth, self.rank, self.num_ranks,
                                        self.strip_rows, self.layout)
-            self._call = (cam, par, C.byref(cam), C.byref(par), C.c_void_p(self.rgb.data_ptr()),
-                          C.c_void_p(self.ids.data_ptr()), C.c_void_p(self.tt.data_ptr()),
-                          C.c_void_p(self.stats.data_ptr()))
-        _, _, cam_p, par_p, rgb_p, id_p, t_p, st_p = self._call
+            ptr = lambda x: C.c_void_p(x.data_ptr()) if x is not None else None
+            self._calls[s] = (cam, par, C.byref(cam), C.byref(par), ptr(sl["rgb"]), ptr(sl["ids"]), ptr(sl["tt"]),
+                              C.c_void_p(self.stats.data_ptr()))
+        _, _, cam_p, par_p, rgb_p, id_p, t_p, st_p = self._calls[s]
         stream = C.c_void_p(self.torch.cuda.current_stream(self.dev).cuda_stream)
         rc = self.ctx._L.mrt_render_device(self.ctx._h, cam_p, par_p, rgb_p, id_p, t_p, st_p if want_stats else None,
                                            stream)
         self.ctx._check(rc, "mrt_render_device")
 
-    def collect(self):
-        """The exchange step + rank 0's scatter (asynchronous on the current stream)."""
+    def render_local(self, want_stats=False):
+        """Enqueue this rank's strips on torch's current stream (asynchronous), into the next set of buffers."""
+        s = self.frames % self.depth
+        self.frames += 1
+        self._render_slot(s, want_stats)
+        return s
+
+    def collect(self, s=None):
+        """The exchange step + rank 0's scatter of the frame in buffer set s (asynchronous on the current stream)."""
         if self.num_ranks == 1:
             return
+        sl = self.slots[(self.frames - 1) % self.depth if s is None else s]
+        ptr = lambda x: x.data_ptr() if x is not None else None
+        stream = self.torch.cuda.current_stream(self.dev).cuda_stream
         if self.comm is not None:
-            stream = self.torch.cuda.current_stream(self.dev).cuda_stream
             if self.rank == 0:
-                self.ctx.gather_strips(self.comm, None, self.staging.data_ptr(), self.rgb.data_ptr(), self.ids.data_ptr(),
-                                       self.tt.data_ptr(), self.W, self.H, self.strip_rows, root_in_place=True,
-                                       stream=stream)
+                self.ctx.gather_strips(self.comm, None, ptr(sl["staging"]), ptr(sl["rgb"]), ptr(sl["ids"]), ptr(sl["tt"]),
+                                       self.W, self.H, self.strip_rows, root_in_place=True, stream=stream,
+                                       planes=self.planes)
             else:
-                self.ctx.gather_strips(self.comm, self.packed.data_ptr(), None, None, None, None, self.W, self.H,
-                                       self.strip_rows, root_in_place=True, stream=stream)
+                self.ctx.gather_strips(self.comm, ptr(sl["buf"]), None, None, None, None, self.W, self.H,
+                                       self.strip_rows, root_in_place=True, stream=stream, planes=self.planes)
             return
-        exchange_packed(self.packed, self.staging, self.offsets, self.rank, self.num_ranks, dst=0)
+        exchange_packed(sl["buf"] if self.rank else None, sl["staging"], self.offsets, self.rank, self.num_ranks, dst=0)
         if self.rank == 0:
-            stream = self.torch.cuda.current_stream(self.dev).cuda_stream
-            self.ctx.scatter_strips(self.staging.data_ptr(), self.rgb.data_ptr(), self.ids.data_ptr(), self.tt.data_ptr(),
-                                    self.W, self.H, self.num_ranks, self.strip_rows, skip_rank=0, stream=stream)
+            self.ctx.scatter_strips(ptr(sl["staging"]), ptr(sl["rgb"]), ptr(sl["ids"]), ptr(sl["tt"]), self.W, self.H,
+                                    self.num_ranks, self.strip_rows, skip_rank=0, stream=stream, planes=self.planes)
 
     def step(self):
-        """One frame: render local strips, send them to rank 0, rank 0 puts them in place.  Asynchronous."""
+        """One frame: render local strips, send them to rank 0, rank 0 puts them in place.  Asynchronous; with
+        pipeline 2 the exchange goes to the side stream and the next step() renders beside it."""
+        if self.depth == 1:
+            self.render_local()
+            self.collect()
+            return
+        torch = self.torch
+        cur = torch.cuda.current_stream(self.dev)
+        s = self.frames % self.depth
+        if self._used[s]:
+            cur.wait_event(self.ev_free[s])     # the exchange that last read (or filled) this set of buffers is over
         self.render_local()
-        self.collect()
+        self.ev_rendered[s].record(cur)
+        self.xstream.wait_event(self.ev_rendered[s])
+        with torch.cuda.stream(self.xstream):
+            self.collect(s)
+        self.ev_free[s].record(self.xstream)
+        self._used[s] = True
 
     def count_rays(self):
         """Blocking: primary/shadow/hit/occluded counts of this rank's strips."""
@@ -184,9 +260,14 @@ class FrameRenderer:
         self.torch.cuda.synchronize(self.dev)
         if self.rank != 0:
             return None
-        return {"rgb": self.rgb.view(self.H, self.W, 3).cpu().numpy(), "id": self.ids.view(self.H, self.W).cpu().numpy(),
-                "t": self.tt.view(self.H, self.W).cpu().numpy()}
+        out = {"rgb": self.rgb.view(self.H, self.W, 3).cpu().numpy()}
+        if self.ids is not None:
+            out["id"] = self.ids.view(self.H, self.W).cpu().numpy()
+        if self.tt is not None:
+            out["t"] = self.tt.view(self.H, self.W).cpu().numpy()
+        return out
 
     def close(self):
+        self.torch.cuda.synchronize(self.dev)
         self.drop_comm()
         self.ctx.close()

@@ -609,6 +609,45 @@ def test_many_cluster_scenes_depth_bounds_and_teams(gpu_ctx, kernel_mode, seed, 
     assert_stats_parity(g["stats"], ref["stats"])
 
 
+@pytest.mark.parametrize("team", [4, 5])
+@pytest.mark.parametrize("seed,lights", [(7, None), (21, 9)])
+def test_team_kernels_at_121_samples(gpu_ctx, kernel_mode, seed, lights, team):
+    """The 121-spp instantiations of the team kernels (render_cull_kernel<true, 1, true, 4, false | true>): what differs
+    from the single-sample path is the reuse of the teams' LDS slots from sample to sample (closest hits, occlusion
+    masks, light contributions) and the barriers around it.  Small frame, thousands of primitives; the second scene has
+    nine lights, from which on teams dealing lights are what the launcher picks by itself.  Against brute force, bit
+    for bit, counters included."""
+    if kernel_mode != "cull":
+        pytest.skip("one comparison: brute force against the tile-culling kernel")
+    spec = _random_scene(seed, 200, 3000)
+    if lights:
+        rng = np.random.default_rng(1000 + seed)
+        ls = []
+        for i in range(lights):
+            v = rng.uniform(-1.0, 1.0, 3)
+            v[1] = abs(v[1]) + 0.5
+            if i % 3:
+                ls.append((capi.LIGHT_POINT, tuple(v * 30.0), tuple(rng.uniform(0.2, 2.0, 3))))
+            else:
+                ls.append((capi.LIGHT_DIRECTIONAL, tuple(-v), tuple(rng.uniform(0.2, 2.0, 3))))
+        spec = scenes.SceneSpec(spec.name, spec.spheres, spec.sphere_obj, spec.tri_verts, spec.tri_obj, spec.mat_kind,
+                                spec.mat_rgb, ls, spec.camera)
+    W, H = 72, 40
+    gpu_ctx.upload(spec.flatten())
+    cam = spec.cam12(W / H)
+    gpu_ctx.set_cull(0)
+    ref = gpu_ctx.render(cam, W, H, spp=121)
+    gpu_ctx.set_cull(2)
+    gpu_ctx.set_cull_team(team)
+    try:
+        g = gpu_ctx.render(cam, W, H, spp=121)
+    finally:
+        gpu_ctx.set_cull_team(0)
+    for k in ("id", "t", "rgb"):
+        assert np.array_equal(g[k], ref[k], equal_nan=True), (k, int((g[k] != ref[k]).sum()))
+    assert_stats_parity(g["stats"], ref["stats"])
+
+
 @pytest.mark.parametrize("seed", range(12))
 def test_random_scenes_both_kernels_vs_oracle(gpu_ctx, seed):
     spec = _random_scene(seed)

@@ -54,6 +54,63 @@ def test_gather_strips_single_rank_through_rccl(gpu_ctx, W, H, strip):
         comm.close()
 
 
+@pytest.mark.parametrize("planes", [capi.PLANE_RGB, capi.PLANE_RGB | capi.PLANE_T, capi.PLANE_RGB | capi.PLANE_ID])
+def test_gather_strips_planes_single_rank_through_rccl(gpu_ctx, planes):
+    """Only some planes travel (mrt_gather_strips_planes): the packed buffer holds rgb, then id / t if gathered; the
+    planes that do not travel keep what the frame buffers held."""
+    torch = pytest.importorskip("torch")
+    W, H, strip = 200, 136, 16
+    flat, _ = scenes.default_scene()
+    gpu_ctx.upload(flat)
+    cam = capi.default_viewport(W / H)
+    full = gpu_ctx.render(cam, W, H)
+    comm = capi.Comm(gpu_ctx, capi.comm_unique_id(), 0, 1)
+    try:
+        n = W * H
+        _, rgb, ids, tt = _frame_buffers(torch, W, H)
+        ids.fill_(-7)
+        has_id, has_t = bool(planes & capi.PLANE_ID), bool(planes & capi.PLANE_T)
+        nd = 3 + has_id + has_t
+        packed = torch.zeros(n * nd, dtype=torch.float32, device="cuda:0")
+        staging = torch.zeros(n * nd, dtype=torch.float32, device="cuda:0")
+        stream = torch.cuda.current_stream().cuda_stream
+        gpu_ctx.render_device(cam, W, H, packed.data_ptr(), id_ptr=packed[n * 3:].data_ptr() if has_id else None,
+                              t_ptr=packed[n * (3 + has_id):].data_ptr() if has_t else None, stream=stream,
+                              strip_rows=strip)
+        gpu_ctx.gather_strips(comm, packed.data_ptr(), staging.data_ptr(), rgb.data_ptr(), ids.data_ptr(),
+                              tt.data_ptr(), W, H, strip_rows=strip, root_in_place=False, stream=stream, planes=planes)
+        torch.cuda.synchronize()
+        assert np.array_equal(rgb.view(H, W, 3).cpu().numpy(), full["rgb"])
+        got_id, got_t = ids.view(H, W).cpu().numpy(), tt.view(H, W).cpu().numpy()
+        assert np.array_equal(got_id, full["id"]) if has_id else bool((got_id == -7).all())
+        assert np.array_equal(got_t, full["t"]) if has_t else bool((got_t == -3.0).all())
+        L = capi.libmrt()
+        assert L.mrt_gather_strips_planes(gpu_ctx._h, comm._h, None, None, C.c_void_p(256), None, None, 64, 64, 8, 1, 6,
+                                          None) == -1  # rgb always travels
+        assert L.mrt_scatter_strips_planes(gpu_ctx._h, C.c_void_p(256), C.c_void_p(256), None, None, 64, 64, 2, 8, 0, 8,
+                                           None) == -1
+    finally:
+        comm.close()
+
+
+def test_render_multi_picture_only(gpu_ctx):
+    """mrt_render_multi with NULL id / t: nothing but the picture is rendered for and copied to the caller."""
+    flat, _ = scenes.default_scene()
+    gpu_ctx.upload(flat)
+    cam = capi.default_viewport(2.0)
+    full = gpu_ctx.render(cam, 256, 128)
+    out = capi.render_multi([gpu_ctx], cam, 256, 128, planes=capi.PLANE_RGB)
+    assert np.array_equal(out["rgb"], full["rgb"]) and bool((out["id"] == -2).all())
+
+
+def test_comm_outlives_its_context():
+    """Either destroy order is allowed (include/mrt.h): the communicator keeps the GPU ordinal itself."""
+    ctx = capi.Context(0)
+    comm = capi.Comm(ctx, capi.comm_unique_id(), 0, 1)
+    ctx.close()
+    comm.close()
+
+
 def test_gather_strips_argument_checks(gpu_ctx):
     L = capi.libmrt()
     comm = capi.Comm(gpu_ctx, capi.comm_unique_id(), 0, 1)

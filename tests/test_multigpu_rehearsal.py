@@ -36,16 +36,49 @@ def _bench(tmp_path, n, config, extra=(), gather=None):
 def test_bench_direct_invocation_with_two_and_four_ranks(tmp_path, config):
     one, f1, _ = _bench(tmp_path, 1, config)
     assert one["n_gpus"] == 1 and one["roofline"]["kernel_ms"] > 0 and one["end_to_end"]["ms"] > 0
+    assert [c["name"] for c in one["configs"]] == [config]
+    if config == "C2":  # small scene: the first-view time beside the repeated-view headline
+        assert one["first_view_ms"] > 0 and one["first_view"]["value"] > 0
     for n in (2, 4):
         js, fn, _ = _bench(tmp_path, n, config)
         assert js["n_gpus"] == n and js["steps"] == 3 and js["value"] > 0
         assert js["config"]["primary_rays"] == one["config"]["primary_rays"]
         assert js["config"]["shadow_rays"] == one["config"]["shadow_rays"]
-        assert "all three gathered" in js["config"]["outputs"]
+        assert js["config"]["outputs"].startswith("rgb+id+t")
+        assert js["multi_gpu"]["pipeline_depth"] == 2 and js["multi_gpu"]["exchange_overlaps_next_render"]
         chk = js["frame_check"]  # the bench's own 1-vs-N comparison, made on rank 0 after the timed region
-        assert chk["rgb_equal"] and chk["id_equal"] and chk["t_equal"], chk
+        assert chk["ok"] and chk["rgb_equal"] and chk["id_equal"] and chk["t_equal"], chk
         for k in ("rgb", "id", "t"):
             assert np.array_equal(fn[k], f1[k]), (n, k)
+
+
+@pytest.mark.timeout(400)
+def test_bench_every_config_in_one_run_at_two_ranks(tmp_path):
+    """The default run measures every workload and reports them in `configs`; here at N = 2 over gloo with the three
+    cheap ones (the 4K scenes and the 121-spp frame take the oracle-free GPU path too, but minutes through the host
+    transfers of a rehearsal).  Every entry carries its own timing, roofline and frame check."""
+    js, _, _ = _bench(tmp_path, 2, "C2,C5,C3", extra=("--blocks", "3"))
+    assert [c["name"] for c in js["configs"]] == ["C2", "C5", "C3"]
+    assert js["value"] == js["configs"][0]["value"] and "frame_check_failed" not in js
+    for c in js["configs"]:
+        assert c["value"] > 0 and c["ms_per_step"] > 0 and c["kernel_ms"] > 0 and c["blocks"]["n"] == 3
+        assert c["blocks"]["ms_per_step_min"] <= c["ms_per_step"] <= c["blocks"]["ms_per_step_max"]
+        assert c["roofline"]["frac"] > 0 and c["frame_check"]["ok"], c
+        assert c["n_gpus"] == 2 and c["multi_gpu"]["planes_gathered"] == "rgb+id+t"
+
+
+@pytest.mark.timeout(400)
+@pytest.mark.parametrize("pipeline", [1, 2])
+def test_bench_picture_only_gather_and_both_pipeline_depths(tmp_path, pipeline):
+    """--planes rgb: the other ranks render and send the picture alone (12 of 20 bytes per pixel); --pipeline 1 | 2:
+    exchange after the render on one stream, or on a side stream beside the next frame's render.  The picture that
+    arrives is the 1-GPU picture in every combination."""
+    one, f1, _ = _bench(tmp_path, 1, "C2")
+    js, fn, _ = _bench(tmp_path, 3, "C2", extra=("--planes", "rgb", "--pipeline", str(pipeline), "--steps", "5"))
+    assert js["multi_gpu"]["planes_gathered"] == "rgb" and js["multi_gpu"]["bytes_per_pixel_gathered"] == 12
+    assert js["multi_gpu"]["pipeline_depth"] == pipeline
+    assert js["frame_check"]["ok"] and "id_equal" not in js["frame_check"]
+    assert np.array_equal(fn["rgb"], f1["rgb"]) and "id" not in fn.files
 
 
 @pytest.mark.timeout(300)

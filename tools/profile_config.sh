@@ -8,6 +8,9 @@ set -e
 tag=$1; cfg=$2; shift 2
 out=$GRAFT_REPO_ROOT/gpurun_out/prof_${tag}_${cfg}
 mkdir -p $out
+# provenance: the hash of the kernel sources this box runs (bench.py compares it with the tree it is run from later
+# and marks the counters stale when they differ); tools/summarize_profile.py adds the git revision
+python3 -c "import sys; sys.path.insert(0, '$GRAFT_REPO_ROOT'); import bench, json; print(json.dumps({'source_hash': bench.source_hash()}))" > $out/provenance.json
 cd /tmp && export TMPDIR=/tmp
 bench="python3 $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --config ${cfg%_brute} $@"
 echo "[profile] $cfg: kernel trace"

@@ -1,6 +1,9 @@
 """Stress run for the bounce kernel: random scenes (mixed diffuse / metallic, point and directional lights) at
-random depths, GPU against the oracle, bit for bit.  usage: python tools/stress_bounce.py <first_seed> <count> [shift [wild]]
-shift: the scene moved by shift * (0.6, -0.4, 1); wild (any fourth argument): stress_common.make_wild per seed."""
+random depths, GPU against the oracle, bit for bit.
+usage: python tools/stress_bounce.py <first_seed> <count> [--shift X] [--wild]
+--shift X: the scene moved by X * (0.6, -0.4, 1); --wild: stress_common.make_wild per seed.  Keywords, so that a
+misplaced word cannot silently become a shift (round 2 lost a run to `... 0 wild`)."""
+import argparse
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, os.path.join(ROOT, "tools"))
@@ -10,9 +13,11 @@ import test_gpu_parity as T
 import _oracle as O
 from stress_common import moved, make_wild
 
-first, count = int(sys.argv[1]), int(sys.argv[2])
-shift = float(sys.argv[3]) if len(sys.argv) > 3 else 0.0
-wild = len(sys.argv) > 4
+_ap = argparse.ArgumentParser()
+_ap.add_argument("first", type=int); _ap.add_argument("count", type=int)
+_ap.add_argument("--shift", type=float, default=0.0); _ap.add_argument("--wild", action="store_true")
+_a = _ap.parse_args()
+first, count, shift, wild = _a.first, _a.count, _a.shift, _a.wild
 ctx = capi.Context(0)
 bad = 0
 t0 = time.time()

@@ -12,13 +12,28 @@ import glob
 import json
 import os
 import shutil
+import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def git_rev():
+    """HEAD (+ "-dirty" when tracked files differ from it) of the tree the profile was taken from: the summaries are
+    made right after the gpurun call, from the same working tree."""
+    try:
+        rev = subprocess.check_output(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], text=True).strip()
+        dirty = subprocess.call(["git", "-C", ROOT, "diff", "--quiet", "HEAD", "--", "raytracing_amd/csrc", "include"]) != 0
+        return rev + ("-dirty" if dirty else "")
+    except (OSError, subprocess.CalledProcessError):
+        return None
+
+
 def main():
     tag, cfgs = sys.argv[1], sys.argv[2:]
+    sys.path.insert(0, ROOT)
+    import bench
+    here_hash, rev = bench.source_hash(), git_rev()
     idx_path = os.path.join(ROOT, "profiles", "counters.json")
     try:
         index = json.load(open(idx_path))
@@ -60,11 +75,20 @@ def main():
             for c in tot:
                 counters[c] = tot[c] / n[c]
                 ndisp[c] = n[c]
+        prov = {}
+        try:
+            prov = json.load(open(os.path.join(d, "provenance.json")))
+        except (OSError, ValueError):
+            pass
+        if prov.get("source_hash") and prov["source_hash"] != here_hash:
+            print(f"WARNING {cfg}: profiled sources {prov['source_hash']} != this tree {here_hash}: the summary is "
+                  f"stamped with the PROFILED hash and bench.py will call it stale")
         entry = {"kernel": kern, "counters_per_dispatch_mean": counters, "dispatches": ndisp,
-                 "how": "tools/profile_config.sh " + tag + " " + cfg}
+                 "how": "tools/profile_config.sh " + tag + " " + cfg,
+                 "source_hash": prov.get("source_hash"), "git_rev": rev}
         out = os.path.join(ROOT, "profiles", f"{tag}_{cfg}_counters.json")
         json.dump(entry, open(out, "w"), indent=1)
-        e = {"source": f"profiles/{tag}_{cfg}_counters.json"}
+        e = {"source": f"profiles/{tag}_{cfg}_counters.json", "source_hash": prov.get("source_hash"), "git_rev": rev}
         if kern:
             e["rocprof_kernel_avg_ns"] = kern["avg_ns"]
             e["kernel"] = kern["name"]
