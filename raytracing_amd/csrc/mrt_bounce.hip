@@ -108,7 +108,7 @@ __device__ __forceinline__ float prm_of(const SmallArgs &s, int f, int lane) { r
 #ifdef MRT_TIMELINE
 // Diagnostic build only (make variant DEFS=-DMRT_TIMELINE; tools/timeline_cull.py REF): per tile the 100 MHz real-time
 // clock at entry and exit of its wave, the shader clock it lived, chain steps | loop iterations.
-enum { TLB_WORDS = 8, TLB_MAX_WAVES = 1 << 17 }; // 4..7: cycles in closest hit | light | push + bounce | fold
+enum { TLB_WORDS = 16, TLB_MAX_WAVES = 1 << 17 }; // 4..7: cycles in sky + select | shading | bounce | fold + loop head; 8..13: finer stamps
 __device__ unsigned long long g_timeline_bounce[TLB_WORDS * TLB_MAX_WAVES];
 extern "C" int mrt_diag_timeline_bounce(unsigned long long *host_out, size_t words)
 {
@@ -138,7 +138,7 @@ __device__ __forceinline__ void render_bounce_body(const Args &S)
   const int tile_y = tile / tiles_x, tile_x = tile - tile_y * tiles_x;
 #ifdef MRT_TIMELINE
   const unsigned long long tl_rt0 = __builtin_amdgcn_s_memrealtime(), tl_c0 = __builtin_amdgcn_s_memtime();
-  unsigned long long tl_acc[4] = {0, 0, 0, 0};
+  unsigned long long tl_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #endif
   const int col = tile_x * 8 + tx;
   const int lrow = tile_y * 8 + ty;
@@ -378,6 +378,7 @@ __device__ __forceinline__ void render_bounce_body(const Args &S)
           if (t < best_t || (t == best_t && t < MRT_INF && obj < best_obj)) { best_t = t; best_obj = obj; best_prim = ns + i; }
         }
       };
+      TLB_MARK(4);
       if (SMALL && primary_iter) {
         unsigned long long mask = primary_mask;
         while (mask) {
@@ -479,6 +480,7 @@ __device__ __forceinline__ void render_bounce_body(const Args &S)
           return true;
         });
       }
+      TLB_MARK(5);
       const bool have_hit = act && best_prim >= 0;
       if (act && depth == 0) { // the ID / t buffers describe the primary hit (of the last sample)
         out_id = have_hit ? best_obj : -1;
@@ -517,6 +519,7 @@ __device__ __forceinline__ void render_bounce_body(const Args &S)
         }
       }
 
+      TLB_MARK(6);
       // ---- shadow rays + direct light at this level: core/light.cuh:135-178 ----
       float lr = 0.0f, lg = 0.0f, lb = 0.0f;
       bool have_light = false;
@@ -587,6 +590,7 @@ __device__ __forceinline__ void render_bounce_body(const Args &S)
             const bool h = (rdn != 0.0f) & (e0 > -1e-6f) & (e1 > -1e-6f) & (e2 > -1e-6f) & (1e-3f <= t) & (t <= tl);
             if (open && h) open = false;
           };
+          TLB_MARK(7);
           if (SMALL) {
             unsigned long long mask = 0;
             if (__any(open)) {
@@ -696,6 +700,7 @@ __device__ __forceinline__ void render_bounce_body(const Args &S)
               return open;
             });
           }
+          TLB_MARK(8);
           if (need) { n_shadow++; if (!open) n_occl++; }
           if (open) {
             // light_bounce with the LIGHT's normal, as the reference passes it (core/light.cuh:164-168);
@@ -748,6 +753,7 @@ __device__ __forceinline__ void render_bounce_body(const Args &S)
           const float s2 = 2.0f * dot3(dx, dy, dz, hnx, hny, hnz);
           bdx = dx - s2 * hnx; bdy = dy - s2 * hny; bdz = dz - s2 * hnz;
         }
+        TLB_MARK(9);
         if (depth + 1 > A.max_depth) { // what the recursive call returns beyond the limit, src/main.cu:51-53
           inr = 0.01f; ing = 0.01f; inb = 0.01f;
           levels = depth + 1;
@@ -796,9 +802,11 @@ __device__ __forceinline__ void render_bounce_body(const Args &S)
 #ifdef MRT_TIMELINE
   if (lane == 0 && tile < TLB_MAX_WAVES) {
     unsigned long long *tlp = g_timeline_bounce + (size_t)TLB_WORDS * tile;
-    tlp[0] = tl_rt0; tlp[1] = __builtin_amdgcn_s_memrealtime(); tlp[2] = __builtin_amdgcn_s_memtime() - tl_c0;
+    // the tile's predicted weight rides in the top byte of the cycle count (the weights sit right below the order)
+    const unsigned long long tl_w = A.tile_order ? (unsigned long long)(A.tile_order - (size_t)tiles_x * tiles_y)[tile] : 0ull;
+    tlp[0] = tl_rt0; tlp[1] = __builtin_amdgcn_s_memrealtime(); tlp[2] = (__builtin_amdgcn_s_memtime() - tl_c0) | (tl_w << 56);
     tlp[3] = (unsigned long long)n_steps | ((unsigned long long)n_iter << 32);
-    for (int k = 0; k < 4; ++k) tlp[4 + k] = tl_acc[k];
+    for (int k = 0; k < 12; ++k) tlp[4 + k] = tl_acc[k];
   }
 #endif
   if (A.stats) {
@@ -822,13 +830,18 @@ __device__ __forceinline__ void render_bounce_body(const Args &S)
 // A pixel's samples share one random stream, so a pixel is a sequential job, and the frame cannot end before its
 // longest job: 121 samples x 9 levels where a mirror faces a metallic sphere.  Waves that start such tiles late
 // leave the GPU idle behind them (7.3 ms in row order, 5.2 ms with the tiles sorted by their measured cost).
-// Cost is predicted here before the frame: 0 for a tile whose primary rays can hit nothing, else 1 + the length of
-// the longest chain among its 64 pixel-centre rays in a one-sample trace with approximate arithmetic, where a
-// diffuse surface bounces along normal + (0.5, 0.5, 0.5), the mean of its random bounce (this only orders the
-// work, results do not depend on it).  Two small kernels turn the
+// Cost is predicted here before the frame: 0 for a tile whose primary rays can hit nothing, else 1 + the largest sum,
+// over the tile's 64 pixels, of the chain lengths of WEIGH_SAMPLES trial samples traced with approximate arithmetic:
+// samples spread over the 11 x 11 mesh, a diffuse surface bouncing along normal + a hashed vector of (0,1)^3 -- a
+// stand-in for the pixel's random stream; this only orders the work, results do not depend on it.  (The first
+// predictor traced ONE sample through the pixel centre with every diffuse bounce along normal + (0.5, 0.5, 0.5): good
+// enough while the frame waited for one wave anyway, but it put a few dozen tiles whose pixels reach the space between
+// the mirrors only through some of their random bounces -- 900-1000 loop iterations -- into the big bucket of 240-
+// iteration tiles, where they started at 2.5 ms of a frame that could have ended at 3.4.)  Two small kernels turn the
 // weights into an order, heaviest bucket first: bounce_count_kernel sizes the buckets, bounce_order_kernel hands
 // out positions.
-enum { ORDER_BUCKETS = 12 };
+enum { WEIGH_SAMPLES = 4, ORDER_BUCKETS = 1 + WEIGH_SAMPLES * MAX_LEVELS + 1 };
+
 
 __global__ __launch_bounds__(256) void bounce_weigh_kernel(SmallArgs S, uint32_t *__restrict__ weight)
 {
@@ -869,60 +882,70 @@ __global__ __launch_bounds__(256) void bounce_weigh_kernel(SmallArgs S, uint32_t
   }
   uint32_t w = 0;
   if (__any(pass)) {
-    w = 1;
-    const float u = float(tile_x * 8 + tx) / float(A.W), v = float(grow0 + ty) / float(A.H);
-    float ox = cam.ox, oy = cam.oy, oz = cam.oz;
-    float dx = ((cam.ux + u * cam.hx) + v * cam.vx) - cam.ox;
-    float dy = ((cam.uy + u * cam.hy) + v * cam.vy) - cam.oy;
-    float dz = ((cam.uz + u * cam.hz) + v * cam.vz) - cam.oz;
-    bool alive = true;
-    for (int level = 0; level <= A.max_depth && __any(alive); ++level) {
-      float best = MRT_INF, nx = 0.0f, ny = 0.0f, nz = 0.0f;
-      int obj = -1;
-      const float aa = dot3(dx, dy, dz, dx, dy, dz);
-      for (int i = 0; i < ns; ++i) {
-        const float cx = sc.sph_cx[i], cy = sc.sph_cy[i], cz = sc.sph_cz[i], r = sc.sph_r[i];
-        const float ocx = ox - cx, ocy = oy - cy, ocz = oz - cz;
-        const float b = dot3(ocx, ocy, ocz, dx, dy, dz), c = dot3(ocx, ocy, ocz, ocx, ocy, ocz) - r * r;
-        const float disc = b * b - aa * c;
-        if (disc >= 0.0f) {
-          const float sq = fast_sqrt(disc), ia = fast_rcp(aa);
-          float t = (-b - sq) * ia;
-          if (!(t >= 0.01f)) t = (-b + sq) * ia;
-          if (t >= 0.01f && t < best) {
-            best = t; obj = sc.sph_obj[i];
-            const float ir = fast_rcp(r);
-            nx = (ox + t * dx - cx) * ir; ny = (oy + t * dy - cy) * ir; nz = (oz + t * dz - cz) * ir;
+    uint32_t steps = 0; // chain steps of this pixel over the trial samples
+    const int nsamp = A.spp > 1 ? WEIGH_SAMPLES : 1;
+    for (int s = 0; s < nsamp; ++s) {
+      // sample positions: mesh cells (1,1), (9,3), (3,9), (7,7) of the 11 x 11 pattern (pipeline/multisample_mesh.cuh)
+      const int mc = s == 0 ? 1 : s == 1 ? 9 : s == 2 ? 3 : 7, mr = s == 0 ? 1 : s == 1 ? 3 : s == 2 ? 9 : 7;
+      float u = float(tile_x * 8 + tx) / float(A.W), v = float(grow0 + ty) / float(A.H);
+      if (A.spp > 1) { u += (-1.0f + 2.0f * float(mc + 1) / 13.0f) / float(A.W); v += (-1.0f + 2.0f * float(mr + 1) / 13.0f) / float(A.H); }
+      float ox = cam.ox, oy = cam.oy, oz = cam.oz;
+      float dx = ((cam.ux + u * cam.hx) + v * cam.vx) - cam.ox;
+      float dy = ((cam.uy + u * cam.hy) + v * cam.vy) - cam.oy;
+      float dz = ((cam.uz + u * cam.hz) + v * cam.vz) - cam.oz;
+      uint32_t h = (uint32_t(tile) * 64u + uint32_t(lane)) * 2654435761u + uint32_t(s) * 0x9E3779B9u; // bounce hash state
+      bool alive = true;
+      for (int level = 0; level <= A.max_depth && __any(alive); ++level) {
+        float best = MRT_INF, nx = 0.0f, ny = 0.0f, nz = 0.0f;
+        int obj = -1;
+        const float aa = dot3(dx, dy, dz, dx, dy, dz);
+        for (int i = 0; i < ns; ++i) {
+          const float cx = sc.sph_cx[i], cy = sc.sph_cy[i], cz = sc.sph_cz[i], r = sc.sph_r[i];
+          const float ocx = ox - cx, ocy = oy - cy, ocz = oz - cz;
+          const float b = dot3(ocx, ocy, ocz, dx, dy, dz), c = dot3(ocx, ocy, ocz, ocx, ocy, ocz) - r * r;
+          const float disc = b * b - aa * c;
+          if (disc >= 0.0f) {
+            const float sq = fast_sqrt(disc), ia = fast_rcp(aa);
+            float t = (-b - sq) * ia;
+            if (!(t >= 0.01f)) t = (-b + sq) * ia;
+            if (t >= 0.01f && t < best) {
+              best = t; obj = sc.sph_obj[i];
+              const float ir = fast_rcp(r);
+              nx = (ox + t * dx - cx) * ir; ny = (oy + t * dy - cy) * ir; nz = (oz + t * dz - cz) * ir;
+            }
+          }
+        }
+        for (int i = 0; i < nt; ++i) {
+          const float *q = sc.tri_rec + 16 * size_t(i);
+          const float rdn = dot3(dx, dy, dz, q[0], q[1], q[2]);
+          const float t = (q[3] - dot3(ox, oy, oz, q[0], q[1], q[2])) * fast_rcp(rdn);
+          const float px = ox + t * dx, py = oy + t * dy, pz = oz + t * dz;
+          const bool hit = rdn != 0.0f && t >= 0.01f && t < best && dot3(q[4], q[5], q[6], px, py, pz) - q[7] > -1e-6f &&
+                           dot3(q[8], q[9], q[10], px, py, pz) - q[11] > -1e-6f &&
+                           dot3(q[12], q[13], q[14], px, py, pz) - q[15] > -1e-6f;
+          if (hit) {
+            best = t; obj = sc.tri_obj[i];
+            const float sgn = rdn < 0.0f ? 1.0f : -1.0f;
+            nx = sgn * q[0]; ny = sgn * q[1]; nz = sgn * q[2];
+          }
+        }
+        if (alive && obj < 0) alive = false; // the sky ends the chain
+        if (alive) {
+          ++steps;
+          ox += best * dx; oy += best * dy; oz += best * dz;
+          if (sc.mat_kind[obj] == 0) { // diffuse: normal + a vector of (0,1)^3
+            h = h * 1664525u + 1013904223u; const float rx = float(h >> 8) * (1.0f / 16777216.0f);
+            h = h * 1664525u + 1013904223u; const float ry = float(h >> 8) * (1.0f / 16777216.0f);
+            h = h * 1664525u + 1013904223u; const float rz = float(h >> 8) * (1.0f / 16777216.0f);
+            dx = nx + rx; dy = ny + ry; dz = nz + rz;
+          } else {
+            const float s2 = 2.0f * dot3(dx, dy, dz, nx, ny, nz);
+            dx -= s2 * nx; dy -= s2 * ny; dz -= s2 * nz;
           }
         }
       }
-      for (int i = 0; i < nt; ++i) {
-        const float *q = sc.tri_rec + 16 * size_t(i);
-        const float rdn = dot3(dx, dy, dz, q[0], q[1], q[2]);
-        const float t = (q[3] - dot3(ox, oy, oz, q[0], q[1], q[2])) * fast_rcp(rdn);
-        const float px = ox + t * dx, py = oy + t * dy, pz = oz + t * dz;
-        const bool hit = rdn != 0.0f && t >= 0.01f && t < best && dot3(q[4], q[5], q[6], px, py, pz) - q[7] > -1e-6f &&
-                         dot3(q[8], q[9], q[10], px, py, pz) - q[11] > -1e-6f &&
-                         dot3(q[12], q[13], q[14], px, py, pz) - q[15] > -1e-6f;
-        if (hit) {
-          best = t; obj = sc.tri_obj[i];
-          const float sgn = rdn < 0.0f ? 1.0f : -1.0f;
-          nx = sgn * q[0]; ny = sgn * q[1]; nz = sgn * q[2];
-        }
-      }
-      if (alive && obj < 0) alive = false; // the sky ends the chain
-      if (alive) {
-        ++w;
-        ox += best * dx; oy += best * dy; oz += best * dz;
-        if (sc.mat_kind[obj] == 0) { // diffuse: the mean of normal + (0,1]^3 stands in for the random bounce
-          dx = nx + 0.5f; dy = ny + 0.5f; dz = nz + 0.5f;
-        } else {
-          const float s2 = 2.0f * dot3(dx, dy, dz, nx, ny, nz);
-          dx -= s2 * nx; dy -= s2 * ny; dz -= s2 * nz;
-        }
-      }
     }
-    w = (uint32_t)wave_max(float(w)); // the tile costs what its longest pixel costs
+    w = 1u + (uint32_t)wave_max(float(steps)); // the tile costs what its longest pixel costs
     if (w > ORDER_BUCKETS - 1) w = ORDER_BUCKETS - 1;
   }
   if (lane == 0) weight[tile] = w;
@@ -1002,8 +1025,9 @@ hipError_t launch_render_bounce(const RenderArgs &in, const SmallHost *hs, uint3
     // many samples per pixel: order the tiles by predicted cost (MRT_BOUNCE_ORDER=0: row by row)
     static const bool ordered = !(getenv("MRT_BOUNCE_ORDER") && atoi(getenv("MRT_BOUNCE_ORDER")) == 0);
     if (scratch && in.spp > 1 && ordered) {
-      uint32_t *count = scratch, *cursor = scratch + 16, *weight = scratch + 64, *order = weight + ntiles;
-      hipError_t e = hipMemsetAsync(scratch, 0, 64 * sizeof(uint32_t), stream);
+      static_assert(2 * ORDER_BUCKETS <= BOUNCE_SCRATCH_HEAD, "bucket counters and cursors sit in the head of the scratch");
+      uint32_t *count = scratch, *cursor = scratch + ORDER_BUCKETS, *weight = scratch + BOUNCE_SCRATCH_HEAD, *order = weight + ntiles;
+      hipError_t e = hipMemsetAsync(scratch, 0, BOUNCE_SCRATCH_HEAD * sizeof(uint32_t), stream);
       if (e != hipSuccess) return e;
       const dim3 pg((ntiles + 255) / 256);
       hipLaunchKernelGGL(bounce_weigh_kernel, grid, block, 0, stream, S, weight);
@@ -1012,6 +1036,10 @@ hipError_t launch_render_bounce(const RenderArgs &in, const SmallHost *hs, uint3
       if ((e = hipGetLastError()) != hipSuccess) return e;
       S.A.tile_order = order;
     }
+    // the two-wave pipeline per tile (mrt_bounce_pipe.hip); MRT_BOUNCE_PIPE=0: the one-wave kernel it replaced
+    // (also MRT_OPT_CULL_TEAM = 1, "one wave per tile": the tests run both)
+    static const bool pipe = !(getenv("MRT_BOUNCE_PIPE") && atoi(getenv("MRT_BOUNCE_PIPE")) == 0);
+    if (pipe && in.team_mode != 1) return launch_render_bounce_pipe(S, stream);
     const dim3 sgrid((ntiles + MRT_BOUNCE_WPB - 1) / MRT_BOUNCE_WPB), sblock(64 * MRT_BOUNCE_WPB);
     if (in.spp > 1) hipLaunchKernelGGL(render_bounce_small_kernel<true>, sgrid, sblock, 0, stream, S);
     else hipLaunchKernelGGL(render_bounce_small_kernel<false>, sgrid, sblock, 0, stream, S);

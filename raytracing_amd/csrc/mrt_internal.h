@@ -147,9 +147,11 @@ inline int uv_table_stride(int W) { return ((W + 31) & ~31) + 128; }
 
 // bounce chains, max_depth 1..8 (mrt_bounce.hip); a scene with a diffuse object needs args.rng; host != null
 // (scenes of at most 64 primitives) lets the primary rays use the small-scene kernel's per-tile culling
-// scratch (device, 4 * tiles + 64 words, or null) lets the launcher order the tiles by predicted cost
+// scratch (device, bounce_scratch_words() words, or null) lets the launcher order the tiles by predicted cost
 hipError_t launch_render_bounce(const RenderArgs &args, const SmallHost *host, uint32_t *scratch, hipStream_t stream);
-inline size_t bounce_scratch_words(int W, int local_rows) { return 4 * (size_t)((W + 7) / 8) * ((local_rows + 7) / 8) + 64; }
+hipError_t launch_render_bounce_pipe(const SmallArgs &S, hipStream_t stream); // mrt_bounce_pipe.hip
+enum { BOUNCE_SCRATCH_HEAD = 128 }; // words ahead of the per-tile arrays: bucket counters and cursors
+inline size_t bounce_scratch_words(int W, int local_rows) { return 4 * (size_t)((W + 7) / 8) * ((local_rows + 7) / 8) + BOUNCE_SCRATCH_HEAD; }
 
 // per-pixel XORWOW streams (mrt_rng.hip): jump matrices A^(2^(67+b)), b < RNG_JUMP_MATRICES, 800 words each
 enum { RNG_JUMP_MATRICES = 32 };

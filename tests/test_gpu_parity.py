@@ -756,6 +756,37 @@ def test_scene_far_from_the_world_origin(gpu_ctx, seed, small, W, H):
     assert_stats_parity(g["stats"], r["stats"])
 
 
+@pytest.mark.parametrize("team", [0, 1])
+def test_bounce_pipeline_and_one_wave_kernel_at_121_samples(gpu_ctx, kernel_mode, team):
+    """Small scenes run their bounce chains as a two-wave pipeline per tile (tracer + shader, mrt_bounce_pipe.hip);
+    MRT_OPT_CULL_TEAM = 1 ("one wave per tile") selects the one-wave kernel it replaced.  The reference's configuration
+    (121 spp, depth 8) on a frame with ragged tiles and a strip of a random small scene with several lights, both
+    kernels against the oracle, bit for bit."""
+    if kernel_mode != "cull":
+        pytest.skip("one pass: both bounce kernels for small scenes are selected by MRT_OPT_CULL_TEAM here")
+    gpu_ctx.set_cull_team(team)
+    try:
+        flat, _ = scenes.default_scene()
+        gpu_ctx.upload(flat)
+        W, H = 72, 40  # a ragged tile column and row
+        cam = capi.default_viewport(W / H)
+        g = gpu_ctx.render(cam, W, H, spp=121, max_depth=8)
+        r = O.Scene.default().render(O.default_viewport(W / H), W, H, spp=121, max_depth=8, nthreads=8)
+        assert_frame_parity(g, r, f"default scene, 121 spp, depth 8, team mode {team}")
+        assert_stats_parity(g["stats"], r["stats"])
+        spec = _random_small_scene(31)
+        gpu_ctx.upload(spec.flatten())
+        W, H = 48, 40
+        cam = spec.cam12(W / H)
+        g = gpu_ctx.render(cam, W, H, spp=121, max_depth=5, rank=1, num_ranks=2, strip_rows=8)
+        r = O.Scene.from_spec(spec).render(cam, W, H, spp=121, max_depth=5, nthreads=8)
+        rows = capi.local_row_index(H, 1, 2, 8)
+        for k in ("id", "t", "rgb"):
+            assert np.array_equal(g[k], r[k][rows], equal_nan=True), (k, team)
+    finally:
+        gpu_ctx.set_cull_team(0)
+
+
 # ------------------------------------------------------------------ mirror chains (max_depth > 0, SURVEY 8(f).1)
 
 def _only_once(kernel_mode):
