@@ -82,7 +82,7 @@ template <> struct CVec<4> { typedef float f __attribute__((ext_vector_type(4)))
 #define MRT_CULL_TEAM_WAVES 1 // 7 fits the team kernels into 72 registers only by spilling to scratch (C4 3 % faster, 0.3 GB of extra writes per frame): left alone
 #endif
 #ifndef MRT_CULL_LSPLIT_WAVES
-#define MRT_CULL_LSPLIT_WAVES 6 // the lights-dealing team kernel sits at 80 / 81 registers: keep it on the 6-wave side
+#define MRT_CULL_LSPLIT_WAVES 6 // measured on the 64-light config: 6 waves with 23 registers spilled (1.163 ms) beat 5 waves with 8 spilled (1.184 ms): the kernel waits on memory, not on issue
 #endif
 template <bool HIER, int P, bool MULTI, int NW, bool LSPLIT = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NW > 1 && !MULTI ? (LSPLIT ? MRT_CULL_LSPLIT_WAVES : MRT_CULL_TEAM_WAVES) : 1, 8)))
@@ -445,6 +445,9 @@ void render_cull_kernel(RenderArgs A)
 #pragma unroll
     for (int p = 0; p < P; ++p) { lr[p] = 0.0f; lg[p] = 0.0f; lb[p] = 0.0f; have_light[p] = false; }
     if (__any(any_hit_lane)) {
+      bool diffuse_obj[P]; // the hit object's material kind: loaded once, used by every light
+#pragma unroll
+      for (int p = 0; p < P; ++p) diffuse_obj[p] = have_hit[p] && sc.mat_kind[best_obj[p]] == 0;
       // ball around the tile's hit points (any subset of them is covered too)
       Bundle B;
       {
@@ -495,7 +498,91 @@ void render_cull_kernel(RenderArgs A)
 
       // One light.  POINT is a compile-time switch: for a directional light the shadow ray direction, its
       // squared length and the light's normal are wave-uniform scalars, for a point light per-pixel registers.
-      auto shade_light = [&](auto point_tag, int li, float lvx, float lvy, float lvz) {
+      // ---- lights dealt among a team (LSPLIT), scenes of at most PRE_MAX_CLUSTERS clusters: what a light's shadow walk
+      //      needs before its first leaf -- the bundle towards the light, its slab, the verdict on every cluster -- is
+      //      computed for a member's lights of a fold chunk AT ONCE, lane = (light, cluster) pair, instead of once per
+      //      light with most lanes idle (64 lights over 8 clusters: 128 set-ups and 512 ball tests per tile, a third
+      //      of the kernel's instructions, become 16 lane-parallel passes).  The light loop fetches its light's values
+      //      from the pair lanes with v_readlane.  The slab's width is bounded through the hit points' extents in the
+      //      tile's own frame (view axis, two perpendiculars: three reductions per tile) instead of a reduction per
+      //      light: |n.e| <= |n.a| Ea + |n.b1| E1 + |n.b2| E2 for every hit point e -- as conservative as before. ----
+      // Scenes of at most 64 clusters (launcher: larger ones under many lights get teams that deal leaves).  A pass covers
+      // 64 / (clusters rounded up to a power of two) lights and is computed when the light loop reaches its first light.
+      const int ncl = sc.ncs + sc.nct;
+      constexpr bool pre_lights = LSPLIT;
+      int pre_shift = 0; // log2 of the lanes per light (clusters rounded up to a power of two)
+      float fb1x = 0.0f, fb1y = 0.0f, fb1z = 0.0f, fb2x = 0.0f, fb2y = 0.0f, fb2z = 0.0f, fEa = 0.0f, fE1 = 0.0f, fE2 = 0.0f;
+      if (pre_lights) {
+        while ((1 << pre_shift) < ncl) ++pre_shift;
+        // the frame: b1 = axis x (the coordinate axis least parallel to it), b2 = axis x b1
+        const bool usex = fabsf(cax) < 0.7f;
+        fb1x = usex ? 0.0f : -caz; fb1y = usex ? caz : 0.0f; fb1z = usex ? -cay : cax; // a x (1,0,0) = (0, az, -ay); a x (0,1,0) = (-az, 0, ax)
+        fast_normalize(fb1x, fb1y, fb1z);
+        fb2x = cay * fb1z - caz * fb1y; fb2y = caz * fb1x - cax * fb1z; fb2z = cax * fb1y - cay * fb1x;
+        // wave-uniform values: keep them in scalar registers across the light loop
+        fb1x = bcast(fb1x, 0); fb1y = bcast(fb1y, 0); fb1z = bcast(fb1z, 0);
+        fb2x = bcast(fb2x, 0); fb2y = bcast(fb2y, 0); fb2z = bcast(fb2z, 0);
+        float ea = 0.0f, e1 = 0.0f, e2 = 0.0f;
+#pragma unroll
+        for (int p = 0; p < P; ++p)
+          if (have_hit[p]) {
+            const float ex = hpx[p] - B.mx, ey = hpy[p] - B.my, ez = hpz[p] - B.mz;
+            ea = fmaxf(ea, fabsf(dot3(cax, cay, caz, ex, ey, ez)));
+            e1 = fmaxf(e1, fabsf(dot3(fb1x, fb1y, fb1z, ex, ey, ez)));
+            e2 = fmaxf(e2, fabsf(dot3(fb2x, fb2y, fb2z, ex, ey, ez)));
+          }
+        fEa = wave_max(ea); fE1 = wave_max(e1); fE2 = wave_max(e2);
+      }
+      // per (light, cluster) pair of the current chunk, in the pair's lane
+      float pDx = 0.0f, pDy = 0.0f, pDz = 0.0f, pDD = 0.0f, pnx = 0.0f, pny = 0.0f, pnz = 0.0f, psw = MRT_INF;
+      float plx = 0.0f, ply = 0.0f, plz = 0.0f, plr = 0.0f, plg = 0.0f, plb = 0.0f; // the pair's light: position / direction, colour
+      int plk = 0;                                                                     // ... and kind
+      unsigned long long pre_mask = 0; // bit = lane = pair: the cluster may be touched by the light's bundle
+      auto precompute_pass = [&](int li0) {
+        // this member's lights from li0 on: li0 + NWS j, j = 0 .. (64 >> pre_shift) - 1
+        const int j = lane >> pre_shift, c = lane & ((1 << pre_shift) - 1);
+        const int li = li0 + NWS * j;
+        const bool okl = li < sc.nl;
+        Bundle Bl = B;
+        Bl.point = false; Bl.Dx = 0.0f; Bl.Dy = 0.0f; Bl.Dz = 0.0f;
+        if (okl) {
+          const float lvx = sc.light_vec[3 * li], lvy = sc.light_vec[3 * li + 1], lvz = sc.light_vec[3 * li + 2];
+          plx = lvx; ply = lvy; plz = lvz; plk = sc.light_kind[li];
+          plr = sc.light_rgb[3 * li]; plg = sc.light_rgb[3 * li + 1]; plb = sc.light_rgb[3 * li + 2];
+          Bl.point = plk != 0;
+          if (!Bl.point) { Bl.Dx = -lvx; Bl.Dy = -lvy; Bl.Dz = -lvz; }
+          else { Bl.Dx = lvx - B.mx; Bl.Dy = lvy - B.my; Bl.Dz = lvz - B.mz; }
+        }
+        Bl.DD = dot3(Bl.Dx, Bl.Dy, Bl.Dz, Bl.Dx, Bl.Dy, Bl.Dz);
+        {
+          float nx = cay * Bl.Dz - caz * Bl.Dy, ny = caz * Bl.Dx - cax * Bl.Dz, nz = cax * Bl.Dy - cay * Bl.Dx;
+          const float nn = dot3(nx, ny, nz, nx, ny, nz);
+          Bl.snx = 0.0f; Bl.sny = 0.0f; Bl.snz = 0.0f; Bl.sw = MRT_INF;
+          if (nn > 2.5e-3f * Bl.DD) { // as bundle_make_slab: below ~3 degrees between axis and light the normal is ill-conditioned
+            const float inv = fast_rsq(nn);
+            nx *= inv; ny *= inv; nz *= inv;
+            const float w = fabsf(dot3(nx, ny, nz, cax, cay, caz)) * fEa + fabsf(dot3(nx, ny, nz, fb1x, fb1y, fb1z)) * fE1 +
+                            fabsf(dot3(nx, ny, nz, fb2x, fb2y, fb2z)) * fE2;
+            Bl.snx = nx; Bl.sny = ny; Bl.snz = nz;
+            Bl.sw = w * (CULL_REL * 1.001f) + CULL_ABS + (Bl.point ? 1e-5f * norm1(Bl.Dx, Bl.Dy, Bl.Dz) : 0.0f);
+          }
+        }
+        bool pass = false;
+        if (okl && c < ncl) {
+          if (c < sc.ncs) {
+            const float x = sc.sph_clu[c], y = sc.sph_clu[sc.ncs + c], z = sc.sph_clu[2 * sc.ncs + c], R = sc.sph_clu[3 * sc.ncs + c];
+            const float wx = x - B.mx, wy = y - B.my, wz = z - B.mz;
+            const float Lm = fast_sqrt(dot3(wx, wy, wz, wx, wy, wz)) * CULL_REL + B.rho + R;
+            pass = bundle_may_touch(Bl, x, y, z, cluster_cull_radius(R, Lm));
+          } else {
+            const int k = c - sc.ncs;
+            pass = bundle_may_touch(Bl, sc.tri_clu[k], sc.tri_clu[sc.nct + k], sc.tri_clu[2 * sc.nct + k], sc.tri_clu[3 * sc.nct + k]);
+          }
+        }
+        pDx = Bl.Dx; pDy = Bl.Dy; pDz = Bl.Dz; pDD = Bl.DD; pnx = Bl.snx; pny = Bl.sny; pnz = Bl.snz; psw = Bl.sw;
+        pre_mask = __ballot(pass);
+      };
+      auto shade_light = [&](auto point_tag, int li, float lvx, float lvy, float lvz, int pj) {
         constexpr bool POINT = decltype(point_tag)::value;
         constexpr int Q = POINT ? P : 1;
         auto ix = [](int p) { return POINT ? p : 0; };
@@ -520,6 +607,13 @@ void render_cull_kernel(RenderArgs A)
           B.point = true;
           B.Dx = lvx - B.mx; B.Dy = lvy - B.my; B.Dz = lvz - B.mz;
         }
+        unsigned long long pre_bits = 0; // clusters the light's bundle may touch (spheres first), when pre-computed
+        if constexpr (LSPLIT) {
+          const int src = (pj << pre_shift) & 63; // the light's first pair lane holds what every pair of the light computed
+          B.Dx = bcast(pDx, src); B.Dy = bcast(pDy, src); B.Dz = bcast(pDz, src); B.DD = bcast(pDD, src);
+          B.snx = bcast(pnx, src); B.sny = bcast(pny, src); B.snz = bcast(pnz, src); B.sw = bcast(psw, src);
+          pre_bits = (pre_mask >> src) & (ncl >= 64 ? ~0ull : (1ull << ncl) - 1ull);
+        } else {
         B.DD = dot3(B.Dx, B.Dy, B.Dz, B.Dx, B.Dy, B.Dz);
         {
           // slab of the bundle for this light (bundle_make_slab, here with P hit points per lane)
@@ -537,6 +631,7 @@ void render_cull_kernel(RenderArgs A)
             B.sw = wave_max(dmax) * CULL_REL + CULL_ABS + (B.point ? 1e-5f * norm1(B.Dx, B.Dy, B.Dz) : 0.0f);
           }
         }
+        }
 #pragma unroll
         for (int q = 0; q < Q; ++q) sa[q] = dot3(sdx[q], sdy[q], sdz[q], sdx[q], sdy[q], sdz[q]);
         bool need[P], open[P], any_open = false;
@@ -551,8 +646,7 @@ void render_cull_kernel(RenderArgs A)
         // any-hit over spheres, interval [1e-3, t_light] (core/light.cuh:28-33)
         const bool team_need = __any(any_open); // from the merged hit records: the same in every member of a team
         leaf_k = 0;
-        if (team_need)
-          walk_hierarchy<HIER>(sc.sph_sclu, sc.nscs, sc.sph_clu, sc.ncs, lane, bundle_vs_sphere_ball, [&](int base) {
+        auto shadow_sphere_leaf = [&](int base) {
             if (!MRT_TEAM_TAKES_SHADOW_LEAF()) return true;
             const int i = base + lane;
             float cx = 0.0f, cy = 0.0f, cz = 0.0f, r = 0.0f;
@@ -585,14 +679,25 @@ void render_cull_kernel(RenderArgs A)
               if (!__any(still)) return false; // ballot early-out
             }
             return true;
-          });
+          };
+        if (team_need) {
+          if constexpr (LSPLIT) { // the clusters this light's bundle may touch were found with the pass's other lights
+            unsigned long long cm = pre_bits & (sc.ncs >= 64 ? ~0ull : (1ull << sc.ncs) - 1ull);
+            while (cm) {
+              const int c = __builtin_ctzll(cm);
+              cm &= cm - 1;
+              if (!shadow_sphere_leaf(c * 64)) break;
+            }
+          } else {
+            walk_hierarchy<HIER>(sc.sph_sclu, sc.nscs, sc.sph_clu, sc.ncs, lane, bundle_vs_sphere_ball, shadow_sphere_leaf);
+          }
+        }
         any_open = false;
 #pragma unroll
         for (int p = 0; p < P; ++p) any_open |= open[p];
         // any-hit over triangles (a member whose sphere walk ended early has met fewer leaves: count afresh)
         leaf_k = 0;
-        if (__any(any_open))
-          walk_hierarchy<HIER>(sc.tri_sclu, sc.nsct, sc.tri_clu, sc.nct, lane, bundle_vs_tri_ball, [&](int base) {
+        auto shadow_triangle_leaf = [&](int base) {
             if (!MRT_TEAM_TAKES_SHADOW_LEAF()) return true;
             const int i = base + lane;
             bool pass = false;
@@ -622,7 +727,19 @@ void render_cull_kernel(RenderArgs A)
               if (!__any(still)) return false;
             }
             return true;
-          });
+          };
+        if (__any(any_open)) {
+          if constexpr (LSPLIT) {
+            unsigned long long cm = sc.ncs >= 64 ? 0ull : pre_bits >> sc.ncs;
+            while (cm) {
+              const int c = __builtin_ctzll(cm);
+              cm &= cm - 1;
+              if (!shadow_triangle_leaf(c * 64)) break;
+            }
+          } else {
+            walk_hierarchy<HIER>(sc.tri_sclu, sc.nsct, sc.tri_clu, sc.nct, lane, bundle_vs_tri_ball, shadow_triangle_leaf);
+          }
+        }
 
         if constexpr (NW > 1 && !LSPLIT) {
           if (team_need) {
@@ -642,7 +759,9 @@ void render_cull_kernel(RenderArgs A)
           }
           if (member != 0) return; // member 0 shades
         }
-        const float lcr = sc.light_rgb[3 * li], lcg = sc.light_rgb[3 * li + 1], lcb = sc.light_rgb[3 * li + 2];
+        float lcr, lcg, lcb;
+        if constexpr (LSPLIT) { const int src = (pj << pre_shift) & 63; lcr = bcast(plr, src); lcg = bcast(plg, src); lcb = bcast(plb, src); }
+        else { lcr = sc.light_rgb[3 * li]; lcg = sc.light_rgb[3 * li + 1]; lcb = sc.light_rgb[3 * li + 2]; }
 #pragma unroll
         for (int p = 0; p < P; ++p) {
           if (need[p] && valid[p]) { n_shadow++; if (!open[p]) n_occl++; }
@@ -650,7 +769,7 @@ void render_cull_kernel(RenderArgs A)
             // light_bounce with the LIGHT's normal, as the reference passes it (core/light.cuh:164-168)
             const float dn = dot3(sdx[ix(p)], sdy[ix(p)], sdz[ix(p)], lnx[ix(p)], lny[ix(p)], lnz[ix(p)]);
             float cr, cg, cb;
-            if (sc.mat_kind[best_obj[p]] == 0) { // DiffuseMaterial::light_bounce, core/material.cuh:63-75
+            if (diffuse_obj[p]) { // DiffuseMaterial::light_bounce, core/material.cuh:63-75
               const float scale = -dn;
               if (scale > 0.0f) { cr = scale * lcr; cg = scale * lcg; cb = scale * lcb; }
               else { cr = 0.0f; cg = 0.0f; cb = 0.0f; }
@@ -677,9 +796,20 @@ void render_cull_kernel(RenderArgs A)
       };
       for (int li = 0; li < sc.nl; ++li) {
         if (!LSPLIT || (li % NWS) == member) {
-          const float lvx = sc.light_vec[3 * li], lvy = sc.light_vec[3 * li + 1], lvz = sc.light_vec[3 * li + 2];
-          if (sc.light_kind[li] == 0) shade_light(std::false_type{}, li, lvx, lvy, lvz);
-          else shade_light(std::true_type{}, li, lvx, lvy, lvz);
+          const int pj = LSPLIT ? li / NWS : -1; // the light's place among this member's lights
+          float lvx, lvy, lvz;
+          int lk;
+          if constexpr (LSPLIT) {
+            if (((pj << pre_shift) & 63) == 0) precompute_pass(li); // the pass that starts with this light
+            const int src = (pj << pre_shift) & 63;                 // ... whose lanes also hold the lights themselves
+            lvx = bcast(plx, src); lvy = bcast(ply, src); lvz = bcast(plz, src);
+            lk = __builtin_amdgcn_readlane(plk, src);
+          } else {
+            lvx = sc.light_vec[3 * li]; lvy = sc.light_vec[3 * li + 1]; lvz = sc.light_vec[3 * li + 2];
+            lk = sc.light_kind[li];
+          }
+          if (lk == 0) shade_light(std::false_type{}, li, lvx, lvy, lvz, pj);
+          else shade_light(std::true_type{}, li, lvx, lvy, lvz, pj);
         }
         if constexpr (LSPLIT) {
           if ((li & (LCH - 1)) == LCH - 1 || li == sc.nl - 1) {
@@ -801,9 +931,11 @@ static int team_mode(const RenderArgs &A)
     return (x == 1 || x == 4 || x == 5) ? x : 0;
   }();
   const int forced = A.team_mode ? A.team_mode : env;
+  if (forced == 5 && A.sc.ncs + A.sc.nct > 64) return 4; // see below
   if (forced) return forced;
-  if (A.sc.nl >= 8) return 5;
-  return (long)A.sc.ns + A.sc.nt >= 100000 ? 4 : 1;
+  // (teams dealing lights set the lights' shadow walks up lane-parallel over (light, cluster) pairs: at most 64 clusters)
+  if (A.sc.nl >= 8 && A.sc.ncs + A.sc.nct <= 64) return 5;
+  return ((long)A.sc.ns + A.sc.nt >= 100000 || A.sc.nl >= 8) ? 4 : 1;
 }
 
 template <bool HIER, int P>

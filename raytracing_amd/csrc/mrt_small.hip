@@ -653,7 +653,48 @@ __device__ __forceinline__ void render_small_body(uint32_t wh, float cone_ext_s,
   if (tl_on && lane == 0) tlp[2] = __builtin_amdgcn_s_memtime();
 #endif
   if ((MRT_ABL & 2) && accr[0] != 1234.5f) return;
-  if (A.wide && valid_row && col0 + P <= A.W) {
+#ifndef MRT_SMALL_LDS_ROWS
+#define MRT_SMALL_LDS_ROWS 0
+#endif
+  // Experiment (make variant DEFS=-DMRT_SMALL_LDS_ROWS=1; round 3, OFF): whole tiles of the two-pixel instantiation write
+  // their RGB rows THROUGH LDS.  A lane's 24 bytes are three dwordx2 at a 24-byte stride, so each of the three store
+  // instructions touches every 64-byte segment of the tile's eight 192-byte rows but fills a third of it; transposed
+  // through LDS the rows go out as 96 pieces of 16 bytes, four lanes to a segment (two instructions).  In a store-only
+  // kernel of this tile shape (tools/ubench_launch.hip) that is worth 2.8 us: 10.2 us as the kernel stores
+  // (non-temporal; 8.1 plain; dwordx4 + dwordx2 or two dwordx3 per lane: no change) against 7.4 us through LDS, which is
+  // the write roof of a frame of this size (one contiguous 41.5 MB fill: 7.2-7.9 us = 5.2-5.8 TB/s).  In THIS kernel it
+  // LOSES 0.8 us (default frame 16.65 against 15.86 us, HIP events; with plain stores 17.2): the LDS round trip and the
+  // wave barrier sit at the end of every wave's life, and the frame is bound by how long its 16 200 waves live, not by
+  // how well their stores combine.
+  constexpr bool LDS_ROWS = MRT_SMALL_LDS_ROWS && P == 2 && LX == 8 && !MULTI;
+  bool lds_rows = false;
+  if constexpr (LDS_ROWS) lds_rows = A.wide && (((uintptr_t)A.rgb & 15) == 0) && ((W & 3) == 0) && __all(valid_row && col0 + P <= A.W);
+  if (LDS_ROWS && lds_rows) {
+    if constexpr (LDS_ROWS) {
+      __shared__ float rgb_rows[8 * 48];
+      float *mine = &rgb_rows[ty * 48 + tx * 6];
+      *reinterpret_cast<float2 *>(mine) = make_float2(accr[0], accg[0]);
+      *reinterpret_cast<float2 *>(mine + 2) = make_float2(accb[0], accr[1]);
+      *reinterpret_cast<float2 *>(mine + 4) = make_float2(accg[1], accb[1]);
+      __builtin_amdgcn_wave_barrier(); // written and read by this wave only
+      const size_t row_base = size_t(A.frame_layout ? grow0 : lrow0); // the tile's first row in the buffers
+      const int tile_col0 = col0 - tx * P;
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int piece = h * 64 + lane; // 96 pieces of 16 bytes, 12 to a row
+        if (piece < 96) {
+          const int r = piece / 12, c = piece - r * 12;
+          const nfloat4 val = *reinterpret_cast<const nfloat4 *>(&rgb_rows[r * 48 + c * 4]);
+          frame_store(val, reinterpret_cast<nfloat4 *>(A.rgb + 3 * ((row_base + r) * A.W + tile_col0) + c * 4));
+        }
+      }
+      using NF = typename VecOf<P>::nf;
+      using NI = typename VecOf<P>::ni;
+      if (A.id) frame_store(*reinterpret_cast<const NI *>(&out_id[0]), reinterpret_cast<NI *>(A.id + pix0));
+      if (A.t) frame_store(*reinterpret_cast<const NF *>(&out_t[0]), reinterpret_cast<NF *>(A.t + pix0));
+      if constexpr (TPW > 1) __builtin_amdgcn_wave_barrier(); // the next tile of the wave writes the rows again
+    }
+  } else if (A.wide && valid_row && col0 + P <= A.W) {
     // the lane's 3P floats / P ints / P floats are contiguous and 4P-byte aligned (launcher checks W and pointers)
     using VF = typename VecOf<P>::f;
     float o[3 * P];

@@ -103,6 +103,61 @@ __global__ __launch_bounds__(64) void store_mode_kernel(float *rgb, int *id, flo
   st2<MODE>(id + pix, a); st2<MODE>(t + pix, b);
 }
 
+// ---- round 3: what bounds the frame's stores? -----------------------------------------------------------------
+// (1) the write roof: the same 41.5 MB written as one contiguous run, 16 bytes per lane and instruction;
+typedef float nfloat3 __attribute__((ext_vector_type(3)));
+template <bool NT>
+__global__ __launch_bounds__(256) void fill_kernel(nfloat4 *dst, size_t n4, int per_thread)
+{
+  size_t i = (size_t)blockIdx.x * blockDim.x * per_thread + threadIdx.x;
+  const nfloat4 v = {1.f, 2.f, 3.f, (float)threadIdx.x};
+  for (int k = 0; k < per_thread; ++k, i += blockDim.x)
+    if (i < n4) { if (NT) __builtin_nontemporal_store(v, dst + i); else dst[i] = v; }
+}
+// (2) the render kernel's tile (8 x 8 lanes, 2 pixels per lane, one wave per workgroup) with the lane's 24 contiguous
+// RGB bytes written as SHAPE 0: three dwordx2 (the kernel's), 1: dwordx4 + dwordx2, 2: two dwordx3,
+// 3: through LDS: the tile's 8 rows of 192 bytes go out as 96 dwordx4 (two instructions, each lane a 16-byte piece of a
+// row: whole 64-byte segments per instruction and row), id and t as they are
+template <int SHAPE, bool NT>
+__global__ __launch_bounds__(64) void store_shape_kernel(float *rgb, int *id, float *t, int W, int H)
+{
+  const int lane = threadIdx.x & 63;
+  const int tx = lane & 7, ty = lane >> 3;
+  const int row0 = blockIdx.y * 8, col00 = blockIdx.x * 16;
+  const int row = row0 + ty, col0 = col00 + tx * 2;
+  if (row0 + 8 > H || col00 + 16 > W) return; // whole tiles only (1920 x 1080 divides)
+  const size_t pix = (size_t)row * W + col0;
+  const float v = (float)(row + col0) * 1e-6f;
+  const float o[6] = {v, v + 1.f, v + 2.f, v + 3.f, v + 4.f, v + 5.f};
+  float *d = rgb + 3 * pix;
+  auto st = [&](auto val, auto *ptr) { if (NT) __builtin_nontemporal_store(val, ptr); else *ptr = val; };
+  if constexpr (SHAPE == 0) {
+    st(nfloat2{o[0], o[1]}, reinterpret_cast<nfloat2 *>(d)); st(nfloat2{o[2], o[3]}, reinterpret_cast<nfloat2 *>(d) + 1);
+    st(nfloat2{o[4], o[5]}, reinterpret_cast<nfloat2 *>(d) + 2);
+  } else if constexpr (SHAPE == 1) { // 24-byte stride: every other lane's dwordx4 sits on an 8-byte boundary only
+    typedef float u4 __attribute__((ext_vector_type(4), aligned(8)));
+    st(u4{o[0], o[1], o[2], o[3]}, reinterpret_cast<u4 *>(d)); st(nfloat2{o[4], o[5]}, reinterpret_cast<nfloat2 *>(d + 4));
+  } else if constexpr (SHAPE == 2) {
+    typedef float u3 __attribute__((ext_vector_type(3), aligned(4)));
+    st(u3{o[0], o[1], o[2]}, reinterpret_cast<u3 *>(d)); st(u3{o[3], o[4], o[5]}, reinterpret_cast<u3 *>(d + 3));
+  } else {
+    __shared__ float tile[8 * 48];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) tile[ty * 48 + tx * 6 + k] = o[k];
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int piece = h * 64 + lane; // 96 pieces of 16 bytes: 12 per row
+      if (piece < 96) {
+        const int r = piece / 12, c = piece - r * 12;
+        const nfloat4 val = *reinterpret_cast<const nfloat4 *>(&tile[r * 48 + c * 4]);
+        st(val, reinterpret_cast<nfloat4 *>(rgb + 3 * ((size_t)(row0 + r) * W + col00) + c * 4));
+      }
+    }
+  }
+  st(nfloat2{v, v}, reinterpret_cast<nfloat2 *>(id + pix)); st(nfloat2{v, v}, reinterpret_cast<nfloat2 *>(t + pix));
+}
+
 template <class F> static float time_us(F launch, int n = 400)
 {
   hipEvent_t e0, e1;
@@ -154,6 +209,28 @@ int main()
   CASE(2, false, 1, 1) CASE(2, true, 1, 1) CASE(2, true, 2, 1) CASE(2, true, 4, 1)
   CASE(2, true, 1, 2) CASE(2, true, 1, 4)
   CASE(4, false, 1, 1) CASE(4, true, 1, 1) CASE(4, true, 4, 1) CASE(4, true, 1, 2) CASE(4, true, 1, 4)
+  printf("the write roof: 41.5 MB as one contiguous run, dwordx4 per lane:\n");
+  {
+    const size_t n4 = (size_t)W * H * 20 / 16;
+    float *lin; CK(hipMalloc(&lin, n4 * 16));
+    for (int per : {1, 4, 16}) {
+      const unsigned blocks = (unsigned)((n4 + 256ull * per - 1) / (256ull * per));
+      float a = time_us([&] { hipLaunchKernelGGL((fill_kernel<false>), dim3(blocks), dim3(256), 0, 0, (nfloat4 *)lin, n4, per); });
+      float b = time_us([&] { hipLaunchKernelGGL((fill_kernel<true>), dim3(blocks), dim3(256), 0, 0, (nfloat4 *)lin, n4, per); });
+      printf("  %2d x 16 B per thread, %6u workgroups of 256: plain %.2f us = %.0f GB/s, nt %.2f us = %.0f GB/s\n", per, blocks, a,
+             W * H * 20.0 / a * 1e-3, b, W * H * 20.0 / b * 1e-3);
+    }
+    CK(hipFree(lin));
+  }
+  printf("16 x 8-pixel tiles, one wave per workgroup, by the shape of the lane's RGB stores:\n");
+  {
+    const char *names[4] = {"3 x dwordx2 (the kernel's)", "dwordx4 + dwordx2", "2 x dwordx3", "rows through LDS, dwordx4"};
+    dim3 g(W / 16, 135);
+#define SHAPE_CASE(S) { float a = time_us([&] { hipLaunchKernelGGL((store_shape_kernel<S, false>), g, dim3(64), 0, 0, rgb, id, t, W, H); }); \
+                        float b = time_us([&] { hipLaunchKernelGGL((store_shape_kernel<S, true>), g, dim3(64), 0, 0, rgb, id, t, W, H); }); \
+                        printf("  %-28s plain %.2f us = %.0f GB/s, nt %.2f us = %.0f GB/s\n", names[S], a, W * H * 20.0 / a * 1e-3, b, W * H * 20.0 / b * 1e-3); }
+    SHAPE_CASE(0) SHAPE_CASE(1) SHAPE_CASE(2) SHAPE_CASE(3)
+  }
   printf("16 x 8-pixel tiles, dwordx2 stores, by cache policy:\n");
   {
     const char *names[8] = {"plain", "nt", "sc0", "sc1", "sc0 sc1", "sc0 nt", "sc1 nt", "sc0 sc1 nt"};
