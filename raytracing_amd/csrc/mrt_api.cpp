@@ -63,6 +63,10 @@ struct mrt_ctx {
   // scratch of the bounce kernel's tile ordering (mrt_bounce.hip), grown on demand
   uint32_t *bounce_scratch = nullptr;
   size_t bounce_scratch_words = 0;
+  // per-frame block lists of the loose triangles (mrt_cull.hip), grown on demand; never by the allocation-free entry
+  void *loose_scratch = nullptr;
+  size_t loose_scratch_bytes = 0;
+  bool no_alloc_call = false; // set around mrt_render_device_static's launch
 
   // Renders of one context share stats_dev and the scratch above, so they are ordered on the GPU: a render on
   // another stream than the last one waits for it (order_after_last).  Buffers a render in flight may still read
@@ -292,7 +296,20 @@ static hipError_t launch_by_mode(mrt_ctx *ctx, mrt::RenderArgs &A, hipStream_t s
   if (mode == 5 && !small) mode = 2;
   switch (mode) {
   case 0: return mrt::launch_render(A, st);
-  case 2: return mrt::launch_render_cull(A, st);
+  case 2: {
+    void *ls = nullptr;
+    const size_t need = ctx->no_alloc_call ? 0 : mrt::loose_scratch_bytes(A);
+    if (need) {
+      if (ctx->loose_scratch_bytes < need) {
+        if ((e = retire(ctx, ctx->loose_scratch, ctx->loose_scratch_bytes)) != hipSuccess) return e;
+        ctx->loose_scratch = nullptr; ctx->loose_scratch_bytes = 0;
+        if ((e = hipMalloc(&ctx->loose_scratch, need)) != hipSuccess) return e;
+        ctx->loose_scratch_bytes = need;
+      }
+      ls = ctx->loose_scratch;
+    }
+    return mrt::launch_render_cull(A, ls, st);
+  }
   default:
     if (!A.utab && (e = ensure_uv_tables(ctx, A.W, A.H, st, &A.utab, &A.vtab)) != hipSuccess) return e;
     return mrt::launch_render_small(A, small_host(ctx), st);
@@ -397,6 +414,7 @@ int mrt_ctx_destroy(mrt_ctx *ctx)
   if (ctx->rng_mem) (void)hipFree(ctx->rng_mem);
   if (ctx->rng_jump) (void)hipFree(ctx->rng_jump);
   if (ctx->bounce_scratch) (void)hipFree(ctx->bounce_scratch);
+  if (ctx->loose_scratch) (void)hipFree(ctx->loose_scratch);
   if (ctx->out_mem) (void)hipFree(ctx->out_mem);
   if (ctx->stats_dev) (void)hipFree(ctx->stats_dev);
   if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
@@ -486,6 +504,7 @@ int mrt_scene_upload(mrt_ctx *ctx, const mrt_scene_desc *s)
 
   std::vector<unsigned char> img;
   try { img.assign(total, 0); } catch (...) { return fail(ctx, MRT_ERR_INVALID, "out of host memory"); }
+  size_t tri_regular = nt; // triangles at the head of the device order that are neither loose nor unbounded
   // host copy of a small scene (device order), committed to the context together with the device scene
   std::vector<float> new_tri16, new_sph;
   std::vector<int32_t> new_tri_obj, new_sph_obj;
@@ -526,7 +545,7 @@ int mrt_scene_upload(mrt_ctx *ctx, const mrt_scene_desc *s)
       tri_bound(q, &tb[4 * i]);
     }
     std::vector<uint32_t> order;
-    primitive_order(nt, [&](size_t i, float *b) { std::memcpy(b, &tb[4 * i], 16); }, order);
+    primitive_order(nt, [&](size_t i, float *b) { std::memcpy(b, &tb[4 * i], 16); }, order, &tri_regular);
     float *tri = (float *)(img.data() + o_tri), *bnd = (float *)(img.data() + o_tb), *rec = (float *)(img.data() + o_trec);
     int32_t *to = (int32_t *)(img.data() + o_to);
     for (size_t i = 0; i < nt; ++i) {
@@ -582,6 +601,7 @@ int mrt_scene_upload(mrt_ctx *ctx, const mrt_scene_desc *s)
   d.tri_shfn = (const float *)(b + o_shfn); d.nls = (int32_t)nls;
   d.sph_clu = (const float *)(b + o_cs); d.ncs = (int32_t)ncs;
   d.tri_clu = (const float *)(b + o_ct); d.nct = (int32_t)nct;
+  d.nct_regular = (int32_t)std::min(nct, (tri_regular + 63) / 64); // clusters from here on hold loose triangles only
   d.sph_sclu = (const float *)(b + o_scs); d.nscs = (int32_t)nscs;
   d.tri_sclu = (const float *)(b + o_sct); d.nsct = (int32_t)nsct;
   d.mat_kind = b + o_mk; d.mat_rgb = (const float *)(b + o_mrgb); d.nobj = (int32_t)no;
@@ -698,7 +718,10 @@ int mrt_render_device_static(mrt_ctx *ctx, const mrt_camera *cam, const mrt_rend
     HIP_TRY(ctx, mrt::launch_uv_table(utab, mrt::uv_table_stride(A.W), A.W, vtab, A.H, A.H, st));
     A.utab = utab; A.vtab = vtab;
   }
-  HIP_TRY(ctx, launch_by_mode(ctx, A, st));
+  ctx->no_alloc_call = true; // nothing below may allocate: the kernels run without their optional scratch buffers
+  const hipError_t le = launch_by_mode(ctx, A, st);
+  ctx->no_alloc_call = false;
+  HIP_TRY(ctx, le);
   if (stats_dev) HIP_TRY(ctx, mrt::launch_stats_reduce(slots, STATS_SLOTS, (unsigned long long *)stats_dev, st));
   return MRT_OK;
 }

@@ -78,12 +78,128 @@ template <> struct CVec<4> { typedef float f __attribute__((ext_vector_type(4)))
 #ifndef MRT_REFINE_EPS
 #define MRT_REFINE_EPS 1e-4f // relative margin of the leaf refinement's edge functions (the exact test rounds at 6e-8)
 #endif
+enum { LOOSE_BLOCK_SHIFT = 6, LOOSE_BLOCK = 1 << LOOSE_BLOCK_SHIFT }; // the loose triangles' lists: one per block of 64 x 64 pixels
 #ifndef MRT_CULL_TEAM_WAVES
 #define MRT_CULL_TEAM_WAVES 1 // 7 fits the team kernels into 72 registers only by spilling to scratch (C4 3 % faster, 0.3 GB of extra writes per frame): left alone
 #endif
 #ifndef MRT_CULL_LSPLIT_WAVES
 #define MRT_CULL_LSPLIT_WAVES 6 // measured on the 64-light config: 6 waves with 23 registers spilled (1.163 ms) beat 5 waves with 8 spilled (1.184 ms): the kernel waits on memory, not on issue
 #endif
+// ---- refinement of a triangle against a pyramid of primary rays (a tile, or a block of tiles) -------------------
+// What the pyramid looks like to the tests below: a cone around it (unit axis, half-angle) for the plane test, its
+// centre ray and half extents along the camera's horizontal / vertical for the screen-space edge functions.
+struct ConeBound {
+  float cax, cay, caz, cosT, sinT;      // cone: unit axis, half-angle (cosT = -1: cannot cull)
+  float dcx, dcy, dcz;                  // centre ray, not normalised
+  float ehx, ehy, ehz, evx, evy, evz;   // half the padded region's extent along the camera's horizontal / vertical
+  float cam_round;                      // rounding of a ray's direction and of the centre ray's (camera_rounding x 2)
+  float dlen_max;                       // max |d| over the region's rays, rounded up
+  float reach_max;                      // depth bound: nothing farther than this (along a ray, in units of length) can win; +inf: none
+};
+
+// Can a ray of the pyramid be accepted by the exact test of triangle i (core/triangle.cuh:77-103)?  false only when
+// provably not; NaN never culls.  Lane-parallel: every lane its own triangle.  AOS: the lanes' triangles are scattered
+// (a list), so each lane reads its 64-byte record (one cache line) instead of 16 strided streams (16 lines).
+template <bool AOS = false>
+__device__ __forceinline__ bool triangle_may_be_hit(const DevScene &sc, const DevCamera &cam, const ConeBound &C, int i)
+{
+  const int nt = sc.nt;
+  float4 rec4[4];
+  if constexpr (AOS) {
+    const float4 *r4 = reinterpret_cast<const float4 *>(sc.tri_rec + 16 * size_t(i));
+#pragma unroll
+    for (int k = 0; k < 4; ++k) rec4[k] = r4[k];
+  }
+  [[maybe_unused]] auto field = [&](int k) { // float k of triangle i's 16
+    const float4 &v = rec4[k >> 2];
+    return (k & 3) == 0 ? v.x : (k & 3) == 1 ? v.y : (k & 3) == 2 ? v.z : v.w;
+  };
+    // Many candidates in one leaf (the usual leaf has one to three): worth a closer look at each, lane-parallel,
+    // before the wave spends a division and up to three edge tests on every one of them for all its pixels.
+    //
+    // (1) The triangle's PLANE against the tile's cone: t = (k - n.o) / (n.d), and over the cone's unit
+    // directions n.u stays within c cos(theta) -+ s sin(theta), c = n.axis, s = |n - c axis|.  If that range
+    // keeps one sign, either every ray of the tile meets the plane behind the camera (the exact test wants
+    // t >= 0.01), or at t >= |k - n.o| / (max |n.u| max |d|): beyond the tile's depth bound it cannot win.
+    // (2) The EDGE planes in screen space (as the small-scene kernel does, mrt_small.hip): with the sign of n.d
+    // fixed, e_i(p) |n.d| = +-w_i.d, w_i = (m_i.o - c_i) n + (k - n.o) m_i, which is affine in the pixel
+    // coordinates: its maximum over the padded tile is its value at the tile's centre plus a constant.  Below
+    // the exact test's -1e-6 (and a margin of 1e-4 of every magnitude that enters either computation; the
+    // exact test rounds at 6e-8): no ray of the tile passes edge i.
+    // This is what deals with triangles that have no finite bound -- the reference's edge planes accept an
+    // unbounded wedge when a triangle's plane passes near the world origin: 223 of the 1M-triangle terrain,
+    // which every tile used to test -- and with the long slivers along a horizon.
+    const size_t snt = size_t(nt);
+    const float pnx = AOS ? field(0) : sc.tri[i], pny = AOS ? field(1) : sc.tri[snt + i], pnz = AOS ? field(2) : sc.tri[2 * snt + i],
+                kp = AOS ? field(3) : sc.tri[3 * snt + i];
+    const float num = kp - dot3(cam.ox, cam.oy, cam.oz, pnx, pny, pnz);
+    const float c = dot3(pnx, pny, pnz, C.cax, C.cay, C.caz);
+    const float qx = pnx - c * C.cax, qy = pny - c * C.cay, qz = pnz - c * C.caz;
+    const float sp = fast_sqrt(dot3(qx, qy, qz, qx, qy, qz));
+    const float pn1 = norm1(pnx, pny, pnz);
+    const float slack = 2e-5f * pn1;
+    const float lo = c * C.cosT - sp * C.sinT - slack, hi = c * C.cosT + sp * C.sinT + slack;
+    if (C.cosT > 0.0f && (lo > 0.0f || hi < 0.0f)) { // (C.cosT = -1: the cone cannot cull)
+      // max |n.u| over the cone: cos(phi - theta) for a normal at angle phi >= theta from the axis -- but a normal
+      // INSIDE the cone (phi < theta: a wall seen head-on, or any normal once rounding has widened the cone far
+      // from the world origin) is some ray's direction, and the maximum is |n|
+      const bool inside = sp * C.cosT <= fabsf(c) * C.sinT * 1.01f + slack;
+      const float big = inside ? pn1 : fmaxf(fabsf(lo), fabsf(hi));
+      const bool behind = (lo > 0.0f) ? (num < 0.0f) : (num > 0.0f);
+      const float o1 = norm1(cam.ox, cam.oy, cam.oz);
+      if (behind && fabsf(num) > 1e-4f * (fabsf(kp) + o1 * pn1)) return false;
+      else if (fabsf(num) * (1.0f - 1e-4f) > C.reach_max * big) return false;
+      {
+        const float sgn = lo > 0.0f ? 1.0f : -1.0f;
+        const float dl = C.dlen_max * 1.01f; // the padded tile's rays are a little longer than the pixels'
+        [[maybe_unused]] const float N1 = fabsf(kp) + pn1 * o1;
+        [[maybe_unused]] const float inv_lo = fast_rcp(fminf(fabsf(lo), fabsf(hi))) * 1.01f; // 1 / min |n.u| over the cone
+#pragma unroll
+        for (int e = 0; e < 3; ++e) {
+          const float mx = AOS ? field(4 + 4 * e) : sc.tri[(4 + 4 * e) * snt + i], my = AOS ? field(5 + 4 * e) : sc.tri[(5 + 4 * e) * snt + i],
+                      mz = AOS ? field(6 + 4 * e) : sc.tri[(6 + 4 * e) * snt + i], ce = AOS ? field(7 + 4 * e) : sc.tri[(7 + 4 * e) * snt + i];
+          const float a = dot3(mx, my, mz, cam.ox, cam.oy, cam.oz) - ce;
+          const float wx = a * pnx + num * mx, wy = a * pny + num * my, wz = a * pnz + num * mz;
+          const float top = sgn * dot3(wx, wy, wz, C.dcx, C.dcy, C.dcz) + fabsf(dot3(wx, wy, wz, C.ehx, C.ehy, C.ehz)) +
+                            fabsf(dot3(wx, wy, wz, C.evx, C.evy, C.evz));
+          const float m1 = norm1(mx, my, mz);
+          // How far can the exact test's fp32 e_i |n.d| be from w_i.d as computed here?  First-order rounding
+          // analysis of both (u = 2^-24 per operation, 1-norms for the sums):
+          //   num = k - n.o        off by 4u N1,  N1 = |k| + |n|1 |o|1
+          //   t = num / (n.d)      relative 4u N1 / |num| + 3u |n|1 |d| / |n.d| + u  -- the middle term is what a
+          //                        grazing ray amplifies: |n.d| >= lo_abs |d| over the cone bounds it
+          //   p = o + t d, e = m.p - c   move by |m.d| |dt| + 5u (|m|1 |o|1 + |m.d| |t|) + u |c|
+          // times |n.d| <= big |d|, plus this block's own a, w and w.d (4u each of their magnitudes):
+          //   u dl [ m1 (8 N1 + 7 |num| + 3.5 |n|1 |num| / lo_abs) + (4 |n|1 + 5 big)(m1 |o|1 + |c|) + 4 |w|1 ]
+          // taken five times over (REFINE_U = 3e-7); then the rounding of the rays themselves (coarse far from the
+          // world origin: camera_rounding) through |w|, and the exact test's own -1e-6.  (Until round 2 this was a
+          // flat 1e-4 of the magnitudes: three times as many candidates on the 1M-triangle terrain.)
+#if MRT_REFINE_RIGOROUS
+          const float w1 = norm1(wx, wy, wz);
+#if MRT_REFINE_MD
+          // the amplified term moves p ALONG THE RAY, so it reaches e_i through |m.d|, not |m| |d|: bound that over
+          // the padded tile (centre value + extents) instead of by norms
+          const float md = (fabsf(dot3(mx, my, mz, C.dcx, C.dcy, C.dcz)) + fabsf(dot3(mx, my, mz, C.ehx, C.ehy, C.ehz)) +
+                            fabsf(dot3(mx, my, mz, C.evx, C.evy, C.evz))) * 1.001f;
+          const float err = MRT_REFINE_U * (dl * m1 * (8.0f * N1 + 7.0f * fabsf(num)) + md * 3.5f * pn1 * fabsf(num) * inv_lo +
+                                            dl * ((4.0f * pn1 + 5.0f * big) * (m1 * o1 + fabsf(ce)) + 4.0f * w1)) +
+                            w1 * C.cam_round + 1e-6f * big * dl;
+#else
+          const float err = MRT_REFINE_U * dl * (m1 * (8.0f * N1 + fabsf(num) * (7.0f + 3.5f * pn1 * inv_lo)) +
+                                                 (4.0f * pn1 + 5.0f * big) * (m1 * o1 + fabsf(ce)) + 4.0f * w1) +
+                            w1 * C.cam_round + 1e-6f * big * dl;
+#endif
+#else
+          const float err = MRT_REFINE_EPS * ((m1 * o1 + fabsf(ce)) * pn1 + fabsf(num) * m1) * (2.0f * dl) +
+                            norm1(wx, wy, wz) * C.cam_round + 1e-6f * big * dl;
+#endif
+          if (top + err < 0.0f) return false; // NaN compares false: never culls
+        }
+      }
+    }
+  return true;
+}
+
 template <bool HIER, int P, bool MULTI, int NW, bool LSPLIT = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NW > 1 && !MULTI ? (LSPLIT ? MRT_CULL_LSPLIT_WAVES : MRT_CULL_TEAM_WAVES) : 1, 8)))
 void render_cull_kernel(RenderArgs A)
@@ -111,8 +227,26 @@ void render_cull_kernel(RenderArgs A)
 
   // 2-D grid: blockIdx.y = tile row, blockIdx.x*4 + wave = tile column (both wave-uniform, so the strip
   // arithmetic below runs on the scalar unit); a team's tile column is its workgroup's index
-  const int tile_x = NW > 1 ? int(blockIdx.x) : int(blockIdx.x * (blockDim.x >> 6) + wave);
-  const int tile_y = blockIdx.y;
+  int tile_x = NW > 1 ? int(blockIdx.x) : int(blockIdx.x * (blockDim.x >> 6) + wave);
+  int tile_y = blockIdx.y;
+  if (A.tile_map) {
+    // XCD-aware order (launcher: 1-D grid).  Workgroups go to the eight XCDs round robin, each with an L2 of its own: in
+    // row order the eight neighbours of a tile -- which open the same leaves -- land on eight different L2s, and every
+    // L2 ends up fetching the whole visible scene.  Here workgroup w serves XCD w % 8, and an XCD takes the frame in
+    // blocks of 8 x 8 tiles dealt to the XCDs in turn: a block's tiles run side by side on ONE L2, and the blocks of
+    // every row of blocks are spread over all eight (sky rows and geometry rows alike, so the XCDs stay balanced).
+    const int bs = 1 << A.tile_map;                              // tiles along a block's side (launcher: 8)
+    const int wg_tiles = NW > 1 ? 1 : int(blockDim.x >> 6);     // tiles of a workgroup, side by side
+    const int upr = bs / wg_tiles;                               // workgroups per row of a block
+    const int txn = (A.W + TW - 1) / TW, tyn = (A.local_rows + 7) >> 3;
+    const int bxn = (txn + bs - 1) >> A.tile_map, nb = bxn * ((tyn + bs - 1) >> A.tile_map);
+    const int w = blockIdx.x, x = w & 7, k = w >> 3;
+    const int b = x + 8 * (k / (bs * upr)), t = k % (bs * upr);
+    if (b >= nb) return;
+    tile_y = (b / bxn) * bs + t / upr;
+    tile_x = (b % bxn) * bs + (t % upr) * wg_tiles + (NW > 1 ? 0 : wave);
+    if (tile_y >= tyn) return;
+  }
   if (tile_x * TW >= A.W) return; // NW == 1: waves are independent; NW > 1: the whole team leaves
   int leaf_k = 0; // leaf clusters met so far in the current walk (the same sequence in every member)
   [[maybe_unused]] int open_set = 0; // which set of tm_open the next merged light uses (the same in every member)
@@ -276,105 +410,29 @@ void render_cull_kernel(RenderArgs A)
     });
 
     // ---- closest hit over triangles: core/triangle.cuh:77-103 ----
-    walk_hierarchy<HIER>(sc.tri_sclu, sc.nsct, sc.tri_clu, sc.nct, lane, tri_ball_in_reach, [&](int base) {
-      if (!MRT_TEAM_TAKES_LEAF()) return true;
-      const int i = base + lane;
-      bool pass = false;
-      if (i < nt) pass = tri_ball_in_reach(sc.tri_bx[i], sc.tri_by[i], sc.tri_bz[i], sc.tri_br[i]);
+    // one batch of up to 64 candidate triangles, lane = triangle i (pass: the lane has one): refinement when the
+    // batch is crowded, then the exact test of every survivor for all pixels
+    // (base >= 0: lane's triangle is base + lane, a leaf of the hierarchy; base < 0: the lanes' triangles come from a list)
+    auto triangle_batch = [&](int i, bool pass, int base) {
       bool moved = false;
       if (HIER && __popcll(__ballot(pass)) >= TRI_REFINE_MIN && pass) {
-        // Many candidates in one leaf (the usual leaf has one to three): worth a closer look at each, lane-parallel,
-        // before the wave spends a division and up to three edge tests on every one of them for all its pixels.
-        //
-        // (1) The triangle's PLANE against the tile's cone: t = (k - n.o) / (n.d), and over the cone's unit
-        // directions n.u stays within c cos(theta) -+ s sin(theta), c = n.axis, s = |n - c axis|.  If that range
-        // keeps one sign, either every ray of the tile meets the plane behind the camera (the exact test wants
-        // t >= 0.01), or at t >= |k - n.o| / (max |n.u| max |d|): beyond the tile's depth bound it cannot win.
-        // (2) The EDGE planes in screen space (as the small-scene kernel does, mrt_small.hip): with the sign of n.d
-        // fixed, e_i(p) |n.d| = +-w_i.d, w_i = (m_i.o - c_i) n + (k - n.o) m_i, which is affine in the pixel
-        // coordinates: its maximum over the padded tile is its value at the tile's centre plus a constant.  Below
-        // the exact test's -1e-6 (and a margin of 1e-4 of every magnitude that enters either computation; the
-        // exact test rounds at 6e-8): no ray of the tile passes edge i.
-        // This is what deals with triangles that have no finite bound -- the reference's edge planes accept an
-        // unbounded wedge when a triangle's plane passes near the world origin: 223 of the 1M-triangle terrain,
-        // which every tile used to test -- and with the long slivers along a horizon.
-        const size_t snt = size_t(nt);
-        const float pnx = sc.tri[i], pny = sc.tri[snt + i], pnz = sc.tri[2 * snt + i], kp = sc.tri[3 * snt + i];
-        const float num = kp - dot3(cam.ox, cam.oy, cam.oz, pnx, pny, pnz);
-        const float c = dot3(pnx, pny, pnz, cax, cay, caz);
-        const float qx = pnx - c * cax, qy = pny - c * cay, qz = pnz - c * caz;
-        const float sp = fast_sqrt(dot3(qx, qy, qz, qx, qy, qz));
-        const float pn1 = norm1(pnx, pny, pnz);
-        const float slack = 2e-5f * pn1;
-        const float lo = c * cosT - sp * sinT - slack, hi = c * cosT + sp * sinT + slack;
-        if (cosT > 0.0f && (lo > 0.0f || hi < 0.0f)) { // (cosT = -1: the cone cannot cull)
-          // max |n.u| over the cone: cos(phi - theta) for a normal at angle phi >= theta from the axis -- but a normal
-          // INSIDE the cone (phi < theta: a wall seen head-on, or any normal once rounding has widened the cone far
-          // from the world origin) is some ray's direction, and the maximum is |n|
-          const bool inside = sp * cosT <= fabsf(c) * sinT * 1.01f + slack;
-          const float big = inside ? pn1 : fmaxf(fabsf(lo), fabsf(hi));
-          const bool behind = (lo > 0.0f) ? (num < 0.0f) : (num > 0.0f);
-          const float o1 = norm1(cam.ox, cam.oy, cam.oz);
-          if (behind && fabsf(num) > 1e-4f * (fabsf(kp) + o1 * pn1)) pass = false;
-          else if (fabsf(num) * (1.0f - 1e-4f) > reach_max * big) pass = false;
-          if (pass) {
-            const float sgn = lo > 0.0f ? 1.0f : -1.0f;
-            const float dl = dlen_max * 1.01f; // the padded tile's rays are a little longer than the pixels'
-            [[maybe_unused]] const float N1 = fabsf(kp) + pn1 * o1;
-            [[maybe_unused]] const float inv_lo = fast_rcp(fminf(fabsf(lo), fabsf(hi))) * 1.01f; // 1 / min |n.u| over the cone
-#pragma unroll
-            for (int e = 0; e < 3; ++e) {
-              const float mx = sc.tri[(4 + 4 * e) * snt + i], my = sc.tri[(5 + 4 * e) * snt + i],
-                          mz = sc.tri[(6 + 4 * e) * snt + i], ce = sc.tri[(7 + 4 * e) * snt + i];
-              const float a = dot3(mx, my, mz, cam.ox, cam.oy, cam.oz) - ce;
-              const float wx = a * pnx + num * mx, wy = a * pny + num * my, wz = a * pnz + num * mz;
-              const float top = sgn * dot3(wx, wy, wz, dcx, dcy, dcz) + fabsf(dot3(wx, wy, wz, ehx, ehy, ehz)) +
-                                fabsf(dot3(wx, wy, wz, evx, evy, evz));
-              const float m1 = norm1(mx, my, mz);
-              // How far can the exact test's fp32 e_i |n.d| be from w_i.d as computed here?  First-order rounding
-              // analysis of both (u = 2^-24 per operation, 1-norms for the sums):
-              //   num = k - n.o        off by 4u N1,  N1 = |k| + |n|1 |o|1
-              //   t = num / (n.d)      relative 4u N1 / |num| + 3u |n|1 |d| / |n.d| + u  -- the middle term is what a
-              //                        grazing ray amplifies: |n.d| >= lo_abs |d| over the cone bounds it
-              //   p = o + t d, e = m.p - c   move by |m.d| |dt| + 5u (|m|1 |o|1 + |m.d| |t|) + u |c|
-              // times |n.d| <= big |d|, plus this block's own a, w and w.d (4u each of their magnitudes):
-              //   u dl [ m1 (8 N1 + 7 |num| + 3.5 |n|1 |num| / lo_abs) + (4 |n|1 + 5 big)(m1 |o|1 + |c|) + 4 |w|1 ]
-              // taken five times over (REFINE_U = 3e-7); then the rounding of the rays themselves (coarse far from the
-              // world origin: camera_rounding) through |w|, and the exact test's own -1e-6.  (Until round 2 this was a
-              // flat 1e-4 of the magnitudes: three times as many candidates on the 1M-triangle terrain.)
-#if MRT_REFINE_RIGOROUS
-              const float w1 = norm1(wx, wy, wz);
-#if MRT_REFINE_MD
-              // the amplified term moves p ALONG THE RAY, so it reaches e_i through |m.d|, not |m| |d|: bound that over
-              // the padded tile (centre value + extents) instead of by norms
-              const float md = (fabsf(dot3(mx, my, mz, dcx, dcy, dcz)) + fabsf(dot3(mx, my, mz, ehx, ehy, ehz)) +
-                                fabsf(dot3(mx, my, mz, evx, evy, evz))) * 1.001f;
-              const float err = MRT_REFINE_U * (dl * m1 * (8.0f * N1 + 7.0f * fabsf(num)) + md * 3.5f * pn1 * fabsf(num) * inv_lo +
-                                                dl * ((4.0f * pn1 + 5.0f * big) * (m1 * o1 + fabsf(ce)) + 4.0f * w1)) +
-                                w1 * cam_round + 1e-6f * big * dl;
-#else
-              const float err = MRT_REFINE_U * dl * (m1 * (8.0f * N1 + fabsf(num) * (7.0f + 3.5f * pn1 * inv_lo)) +
-                                                     (4.0f * pn1 + 5.0f * big) * (m1 * o1 + fabsf(ce)) + 4.0f * w1) +
-                                w1 * cam_round + 1e-6f * big * dl;
-#endif
-#else
-              const float err = MRT_REFINE_EPS * ((m1 * o1 + fabsf(ce)) * pn1 + fabsf(num) * m1) * (2.0f * dl) +
-                                norm1(wx, wy, wz) * cam_round + 1e-6f * big * dl;
-#endif
-              if (top + err < 0.0f) pass = false; // NaN compares false: never culls
-            }
-          }
-        }
+        ConeBound CB;
+        CB.cax = cax; CB.cay = cay; CB.caz = caz; CB.cosT = cosT; CB.sinT = sinT;
+        CB.dcx = dcx; CB.dcy = dcy; CB.dcz = dcz;
+        CB.ehx = ehx; CB.ehy = ehy; CB.ehz = ehz; CB.evx = evx; CB.evy = evy; CB.evz = evz;
+        CB.cam_round = cam_round; CB.dlen_max = dlen_max; CB.reach_max = reach_max;
+        pass = base >= 0 ? triangle_may_be_hit<false>(sc, cam, CB, i) : triangle_may_be_hit<true>(sc, cam, CB, i);
       }
       unsigned long long mask = __ballot(pass);
       n_clusters++; n_exact += __popcll(mask);
       while (mask) {
         const int j = __builtin_ctzll(mask);
         mask &= mask - 1;
-        const float *q = sc.tri_rec + 16 * size_t(base + j); // wave-uniform address: one s_load_dwordx16
+        const int tj = base >= 0 ? base + j : __builtin_amdgcn_readlane(i, j);  // lane j's triangle
+        const float *q = sc.tri_rec + 16 * size_t(tj);   // wave-uniform address: one s_load_dwordx16
         const float pnx = q[0], pny = q[1], pnz = q[2], kp = q[3];
         const float num = kp - dot3(cam.ox, cam.oy, cam.oz, pnx, pny, pnz);
-        const int obj = sc.tri_obj[base + j];
+        const int obj = sc.tri_obj[tj];
 #pragma unroll
         for (int p = 0; p < P; ++p) {
           const float rdn = dot3(dx[p], dy[p], dz[p], pnx, pny, pnz);
@@ -390,14 +448,46 @@ void render_cull_kernel(RenderArgs A)
           const bool hit = (rdn != 0.0f) & (e0 > -1e-6f) & (e1 > -1e-6f) & (e2 > -1e-6f) & (0.01f <= t) & (t <= MRT_INF);
           if (hit) {
             if (t < best_t[p] || (t == best_t[p] && t < MRT_INF && obj < best_obj[p])) {
-              best_t[p] = t; best_obj[p] = obj; best_prim[p] = ns + base + j; moved = true;
+              best_t[p] = t; best_obj[p] = obj; best_prim[p] = ns + tj; moved = true;
             }
           }
         }
       }
       if (NW == 1 && __any(moved)) refresh_reach();
+    };
+    // The LOOSE triangles -- the tail of the triangle order (mrt_scene_build.h): long wedges and unbounded regions that
+    // the reference's edge planes accept, whose bounding balls every tile's cone touches -- come from a list per
+    // 64 x 64-pixel block instead (bin_loose_kernel, once per frame): the tile refines only what its block kept.
+    const bool use_lists = HIER && A.loose_cnt != nullptr; // wave-uniform
+    walk_hierarchy<HIER>(sc.tri_sclu, sc.nsct, sc.tri_clu, sc.nct, lane, tri_ball_in_reach, [&](int base) {
+      if (!MRT_TEAM_TAKES_LEAF()) return true;
+      const int i = base + lane;
+      bool pass = false;
+      if (i < nt) pass = tri_ball_in_reach(sc.tri_bx[i], sc.tri_by[i], sc.tri_bz[i], sc.tri_br[i]);
+      triangle_batch(i, pass, base);
       return true;
-    });
+    }, use_lists ? A.loose_nct_walk : -1);
+    if constexpr (HIER) {
+      if (use_lists) {
+        const int blk = (grow0 >> LOOSE_BLOCK_SHIFT) * A.loose_bx + ((tile_x * TW) >> LOOSE_BLOCK_SHIFT);
+        const uint32_t cnt = A.loose_cnt[blk];
+        const int first = A.loose_nct_walk * 64; // the first listed triangle
+        if (cnt > (uint32_t)A.loose_cap) {
+          // the block's list overflowed: its tiles take every loose triangle, batch by batch, as they used to
+          for (int base = first; base < nt; base += 64) {
+            if (!MRT_TEAM_TAKES_LEAF()) continue;
+            triangle_batch(base + lane, base + lane < nt, base);
+          }
+        } else {
+          const uint16_t *list = A.loose_list + size_t(blk) * A.loose_cap;
+          for (uint32_t k0 = 0; k0 < cnt; k0 += 64) {
+            if (!MRT_TEAM_TAKES_LEAF()) continue;
+            const bool have = k0 + lane < cnt;
+            triangle_batch(have ? first + int(list[k0 + lane]) : first, have, -1);
+          }
+        }
+      }
+    }
 
     if constexpr (NW > 1) {
       // the team's closest hit: the minimum of the members' (t, object) under the same rule as inside a member
@@ -915,6 +1005,76 @@ void render_cull_kernel(RenderArgs A)
   }
 }
 
+// ---- the loose triangles' lists: which of them can a ray of each 64 x 64-pixel block meet? ---------------------
+// One wave per (block, 64 loose triangles), lane = triangle: the refinement the tiles use (triangle_may_be_hit: plane
+// against the block's cone, edge planes in screen space over the padded block), without a depth bound.  A block's
+// pyramid holds the pyramids of its 64 tiles, padding included, so whatever a tile could not exclude its block cannot
+// exclude either.  Survivors are appended to the block's list (one atomic per wave); a list that outgrows its
+// capacity only keeps counting, and the block's tiles then take every loose triangle as before.
+__global__ __launch_bounds__(256) void bin_loose_kernel(RenderArgs A, float block_cone_ext, uint16_t *__restrict__ list,
+                                                        uint32_t *__restrict__ cnt)
+{
+  const DevScene &sc = A.sc;
+  const DevCamera &cam = A.cam;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int blk = blockIdx.x, by = blk / A.loose_bx, bx = blk - by * A.loose_bx;
+  const int first = A.loose_nct_walk * 64;
+  const int i = first + (int(blockIdx.y) * 4 + wave) * 64 + lane;
+  if (first + (int(blockIdx.y) * 4 + wave) * 64 >= sc.nt) return;
+  ConeBound C;
+  {
+    const float rw = fast_rcp(float(A.W)), rh = fast_rcp(float(A.H));
+    const float um = (float(bx * LOOSE_BLOCK) + 0.5f * float(LOOSE_BLOCK - 1)) * rw, vm = (float(by * LOOSE_BLOCK) + 0.5f * float(LOOSE_BLOCK - 1)) * rh;
+    C.dcx = ((cam.ux + um * cam.hx) + vm * cam.vx) - cam.ox;
+    C.dcy = ((cam.uy + um * cam.hy) + vm * cam.vy) - cam.oy;
+    C.dcz = ((cam.uz + um * cam.hz) + vm * cam.vz) - cam.oz;
+    C.cam_round = 2.0f * camera_rounding(cam);
+    const float du = (0.5f * float(LOOSE_BLOCK) + 0.51f) * rw * 1.001f, dv = (0.5f * float(LOOSE_BLOCK) + 0.51f) * rh * 1.001f; // pixels -1 .. 64
+    C.ehx = du * cam.hx; C.ehy = du * cam.hy; C.ehz = du * cam.hz;
+    C.evx = dv * cam.vx; C.evy = dv * cam.vy; C.evz = dv * cam.vz;
+    const float dd = dot3(C.dcx, C.dcy, C.dcz, C.dcx, C.dcy, C.dcz);
+    const float inv = fast_rsq(dd);
+    C.cax = C.dcx * inv; C.cay = C.dcy * inv; C.caz = C.dcz * inv;
+    C.sinT = block_cone_ext * inv * (1.0f + 1e-4f) + 1e-6f;
+    C.cosT = fast_sqrt(fmaxf(1.0f - C.sinT * C.sinT, 0.0f)) * (1.0f - 1e-5f) - 1e-6f;
+    if (!(C.sinT < 0.99f) || !(C.cosT > 0.0f)) { C.cosT = -1.0f; C.sinT = 0.0f; } // cannot cull
+    // no ray of the padded block is longer than the centre ray plus the two half extents
+    C.dlen_max = (fast_sqrt(dd) + fast_sqrt(dot3(C.ehx, C.ehy, C.ehz, C.ehx, C.ehy, C.ehz)) +
+                  fast_sqrt(dot3(C.evx, C.evy, C.evz, C.evx, C.evy, C.evz))) * (1.0f + 1e-4f);
+    C.reach_max = MRT_INF;
+  }
+  const bool pass = i < sc.nt && triangle_may_be_hit(sc, cam, C, i);
+  const unsigned long long mask = __ballot(pass);
+  if (!mask) return;
+  uint32_t base = 0;
+  if (lane == 0) base = atomicAdd(&cnt[blk], (uint32_t)__popcll(mask));
+  base = __builtin_amdgcn_readfirstlane(base);
+  if (pass) {
+    const uint32_t pos = base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+    if (pos < (uint32_t)A.loose_cap) list[size_t(blk) * A.loose_cap + pos] = (uint16_t)(i - first);
+  }
+}
+
+// entries per block: lists longer than this send the block's tiles back to the loose clusters themselves
+#ifndef MRT_LOOSE_CAP
+#define MRT_LOOSE_CAP 2048
+#endif
+// Lists pay when there are loose clusters to skip, few enough loose triangles for 16-bit entries, and frames of
+// more than a few blocks.  MRT_LOOSE_LISTS=0 switches them off (ablation).
+static bool loose_lists_apply(const RenderArgs &A)
+{
+  static const bool on = !(getenv("MRT_LOOSE_LISTS") && atoi(getenv("MRT_LOOSE_LISTS")) == 0);
+  static const long least = getenv("MRT_LOOSE_MIN") ? atol(getenv("MRT_LOOSE_MIN")) : 256; // (stress runs: 1)
+  const long nloose = (long)A.sc.nt - (long)A.sc.nct_regular * 64;
+  return on && A.sc.nct > 1 && A.sc.nct_regular < A.sc.nct && nloose >= least && nloose <= 65536 && A.spp == 1;
+}
+size_t loose_scratch_bytes(const RenderArgs &A)
+{
+  if (!loose_lists_apply(A)) return 0;
+  const size_t blocks = size_t((A.W + LOOSE_BLOCK - 1) / LOOSE_BLOCK) * size_t((A.H + LOOSE_BLOCK - 1) / LOOSE_BLOCK);
+  return ((blocks * 4 + 255) / 256) * 256 + blocks * MRT_LOOSE_CAP * 2;
+}
+
 // Waves per tile for a scene (render_cull_kernel's NW and LSPLIT).  A team pays for itself when single tiles are long
 // jobs: many lights (every hit tile walks the scene once per light) or a very large scene (tiles along a horizon
 // open hundreds of clusters).  Measured (tools/timeline_cull.py): 64 point lights over 512 primitives
@@ -956,12 +1116,22 @@ static hipError_t launch_cull(RenderArgs &A, hipStream_t stream)
            ((uintptr_t)A.t & align) == 0;
   const int tiles_x = (A.W + 8 * P - 1) / (8 * P), tiles_y = (A.local_rows + 7) / 8;
   if (tiles_x == 0 || tiles_y == 0) return hipSuccess;
+  // XCD-aware tile order for scenes with a hierarchy (their leaves are what neighbouring tiles share); MRT_CULL_XCD=0: rows
+  // (MRT_CULL_XCD = n: blocks of 2^n x 2^n tiles, whatever the scene; 0: rows.)  By default for scenes that do not fit an
+  // L2 (from 100 000 primitives on): the 1M-triangle terrain 2.61 -> 2.41 ms; scenes that do fit lose 1-3 % to the
+  // coarser interleaving of cheap and expensive tiles (10k spheres 421 -> 432 us, 64 lights 1141 -> 1155 us).
+  static const int xcd = getenv("MRT_CULL_XCD") ? atoi(getenv("MRT_CULL_XCD")) : -1;
+  A.tile_map = !HIER ? 0 : xcd >= 0 ? (xcd > 6 ? 6 : xcd) : ((long)A.sc.ns + A.sc.nt >= 100000 ? 3 : 0);
   // waves per workgroup: waves share nothing; 2 measured best on C3 and C5 (413 / 1561 us against 444 / 1625 with 4)
   static const int wpw = getenv("MRT_CULL_WPW") ? atoi(getenv("MRT_CULL_WPW")) : 2;
   if constexpr (HIER && P == 1) {
     const int team = team_mode(A);
     if (team != 1) { // one workgroup of four waves per tile
-      const dim3 tgrid(tiles_x, tiles_y);
+      dim3 tgrid(tiles_x, tiles_y);
+      if (A.tile_map) {
+        const unsigned bs = 1u << A.tile_map;
+        tgrid = dim3(8u * bs * bs * (unsigned)((((tiles_x + bs - 1) / bs) * ((tiles_y + bs - 1) / bs) + 7) / 8));
+      }
       if (team == 5) {                  // the members deal the lights
         if (A.spp > 1) hipLaunchKernelGGL((render_cull_kernel<true, 1, true, 4, true>), tgrid, dim3(256), 0, stream, A);
         else hipLaunchKernelGGL((render_cull_kernel<true, 1, false, 4, true>), tgrid, dim3(256), 0, stream, A);
@@ -972,15 +1142,46 @@ static hipError_t launch_cull(RenderArgs &A, hipStream_t stream)
       return hipGetLastError();
     }
   }
-  const dim3 grid((tiles_x + wpw - 1) / wpw, tiles_y);
+  dim3 grid((tiles_x + wpw - 1) / wpw, tiles_y);
+  if (A.tile_map) {
+    const unsigned bs = 1u << A.tile_map;
+    if (wpw == 1 || wpw == 2 || wpw == 4 || wpw == 8)
+      grid = dim3(8u * (bs * bs / (unsigned)wpw) * (unsigned)((((tiles_x + bs - 1) / bs) * ((tiles_y + bs - 1) / bs) + 7) / 8));
+    else A.tile_map = 0;
+  }
   if (A.spp > 1) hipLaunchKernelGGL((render_cull_kernel<HIER, P, true, 1>), grid, dim3(64 * wpw), 0, stream, A);
   else hipLaunchKernelGGL((render_cull_kernel<HIER, P, false, 1>), grid, dim3(64 * wpw), 0, stream, A);
   return hipGetLastError();
 }
 
-hipError_t launch_render_cull(const RenderArgs &in, hipStream_t stream)
+hipError_t launch_render_cull(const RenderArgs &in, hipStream_t stream) { return launch_render_cull(in, nullptr, stream); }
+
+hipError_t launch_render_cull(const RenderArgs &in, void *loose_scratch, hipStream_t stream)
 {
   RenderArgs A = in;
+  A.loose_list = nullptr; A.loose_cnt = nullptr;
+  if (loose_scratch && loose_lists_apply(A)) {
+    const int bx = (A.W + LOOSE_BLOCK - 1) / LOOSE_BLOCK, by = (A.H + LOOSE_BLOCK - 1) / LOOSE_BLOCK;
+    const size_t blocks = size_t(bx) * by;
+    uint32_t *cnt = (uint32_t *)loose_scratch;
+    uint16_t *list = (uint16_t *)((char *)loose_scratch + ((blocks * 4 + 255) / 256) * 256);
+    // (MRT_LOOSE_CAP in the environment shortens the lists: stress runs use it to reach the overflow path)
+    static const int cap_env = getenv("MRT_LOOSE_CAP") ? atoi(getenv("MRT_LOOSE_CAP")) : MRT_LOOSE_CAP;
+    A.loose_bx = bx; A.loose_cap = cap_env < 1 ? 1 : (cap_env > MRT_LOOSE_CAP ? MRT_LOOSE_CAP : cap_env);
+    A.loose_nct_walk = A.sc.nct_regular; A.loose_nsct_walk = (A.sc.nct_regular + 63) / 64;
+    // the padded block's largest offset from its centre ray (as launch_cull does for a tile), in double, rounded up
+    const double hw = (0.5 * LOOSE_BLOCK + 0.5) / A.W, hh = (0.5 * LOOSE_BLOCK + 0.5) / A.H;
+    const double hx[3] = {hw * A.cam.hx, hw * A.cam.hy, hw * A.cam.hz}, hy[3] = {hh * A.cam.vx, hh * A.cam.vy, hh * A.cam.vz};
+    double pp = 0, mm = 0;
+    for (int k = 0; k < 3; ++k) { pp += (hx[k] + hy[k]) * (hx[k] + hy[k]); mm += (hx[k] - hy[k]) * (hx[k] - hy[k]); }
+    const float block_ext = float(std::sqrt(pp > mm ? pp : mm) * 1.001) + 2.0f * camera_rounding(A.cam);
+    hipError_t e = hipMemsetAsync(cnt, 0, blocks * 4, stream);
+    if (e != hipSuccess) return e;
+    const long nloose = (long)A.sc.nt - (long)A.sc.nct_regular * 64;
+    hipLaunchKernelGGL(bin_loose_kernel, dim3((unsigned)blocks, (unsigned)((nloose + 255) / 256)), dim3(256), 0, stream, A, block_ext, list, cnt);
+    if ((e = hipGetLastError()) != hipSuccess) return e;
+    A.loose_list = list; A.loose_cnt = cnt;
+  }
   // pixels per lane.  Measured: with a hierarchy to walk, one pixel per lane (72 registers, 7 waves
   // per SIMD) beats two on every large config but C3, where the two are even; without one, two win.
   // MRT_CULL_P = 1 | 2 overrides (ablation).

@@ -158,31 +158,35 @@ __device__ __forceinline__ bool bundle_may_touch(const Bundle &B, float cx, floa
 // level: 64 super-clusters per step, then the 64 clusters of each surviving super-cluster, then
 // body(first primitive of the cluster) for each surviving cluster.  A level with a single entry is not
 // tested (tiny scenes: C2).  body returns false to stop the walk (shadow early-out).
+// n: balls at this level (the streams' stride); limit <= n: only balls below it are visited
 template <class Test>
 __device__ __forceinline__ unsigned long long level_mask(const float *__restrict__ balls, int n, int begin, int lane,
-                                                         Test test)
+                                                         Test test, int limit)
 {
-  if (n == 1) return 1ull;
+  if (n == 1) return limit > 0 ? 1ull : 0ull;
   const int i = begin + lane;
   bool pass = false;
-  if (i < min(n, begin + 64)) pass = test(balls[i], balls[n + i], balls[2 * n + i], balls[3 * n + i]);
+  if (i < min(limit, begin + 64)) pass = test(balls[i], balls[n + i], balls[2 * n + i], balls[3 * n + i]);
   return __ballot(pass);
 }
 
+// nc_limit (optional, <= nc): the walk covers clusters 0 .. nc_limit - 1 only
 template <bool HIER, class Test, class Body>
 __device__ __forceinline__ void walk_hierarchy(const float *__restrict__ sclu, int nsc, const float *__restrict__ clu,
-                                               int nc, int lane, Test test, Body body)
+                                               int nc, int lane, Test test, Body body, int nc_limit = -1)
 {
   if (!HIER) { // at most one cluster per primitive type (C2): nothing to walk
     if (nc > 0) body(0);
     return;
   }
-  for (int sb = 0; sb < nsc; sb += 64) {
-    unsigned long long smask = level_mask(sclu, nsc, sb, lane, test);
+  if (nc_limit < 0) nc_limit = nc;
+  const int nsc_limit = (nc_limit + 63) >> 6;
+  for (int sb = 0; sb < nsc_limit; sb += 64) {
+    unsigned long long smask = level_mask(sclu, nsc, sb, lane, test, nsc_limit);
     while (smask) {
       const int cb = (sb + __builtin_ctzll(smask)) * 64;
       smask &= smask - 1;
-      unsigned long long cmask = level_mask(clu, nc, cb, lane, test);
+      unsigned long long cmask = level_mask(clu, nc, cb, lane, test, nc_limit);
       while (cmask) {
         const int base = (cb + __builtin_ctzll(cmask)) * 64;
         cmask &= cmask - 1;

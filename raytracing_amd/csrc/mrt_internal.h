@@ -35,6 +35,7 @@ struct DevScene {
   const float *sph_sclu, *tri_sclu;
   int32_t nscs, nsct;
   int32_t nt;
+  int32_t nct_regular; // triangle clusters ahead of the first one that holds loose / unbounded triangles only (== nct: none)
   // per object material (core/material.cuh:78,160)
   const uint8_t *mat_kind;
   const float *mat_rgb; // [nobj*3]
@@ -88,6 +89,7 @@ struct RenderArgs {
   const float *utab, *vtab;
   int32_t wide;
   float cone_ext;                   // cull kernel: max |ray - tile centre ray| over a padded tile (launcher)
+  int32_t tile_map;                 // cull kernel: 0 tiles in row order (2-D grid), n: XCD-aware blocks of 2^n x 2^n tiles (1-D grid)
   int32_t team_mode;                // cull kernel, MRT_OPT_CULL_TEAM: 0 automatic, 1 one wave per tile, 4 teams dealing leaves, 5 dealing lights
   // diffuse bounces (mrt_bounce.hip, mrt_rng.hip): xorshift words of pixel i at rng[k * rng_stride + i], k = 0..4,
   // and the Weyl counter every stream starts with; null when no stream is needed
@@ -95,9 +97,19 @@ struct RenderArgs {
   uint32_t rng_stride, rng_d;
   // bounce kernel: wave w renders tile tile_order[w] (null: tile w); tiles are numbered row by row
   const uint32_t *tile_order;
+  // cull kernel, primary rays: the loose triangles (those from cluster loose_nct_walk on) per block of 64 x 64 pixels of
+  // the frame -- loose_cnt[block] entries (16-bit offsets from the first loose triangle) at loose_list + block *
+  // loose_cap; a count above loose_cap = the list overflowed, take them all.  Null: no lists, the walk covers everything.
+  const uint16_t *loose_list;
+  const uint32_t *loose_cnt;
+  int32_t loose_bx, loose_cap;          // blocks per row of blocks; entries per block
+  int32_t loose_nct_walk, loose_nsct_walk; // clusters / super-clusters the hierarchy walk still covers
 };
 
 hipError_t launch_render_cull(const RenderArgs &args, hipStream_t stream);
+// per-frame scratch of the loose triangles' block lists (device; loose_scratch_bytes() of it, or null = no lists)
+size_t loose_scratch_bytes(const RenderArgs &args);
+hipError_t launch_render_cull(const RenderArgs &args, void *loose_scratch, hipStream_t stream);
 
 // scenes of at most 64 primitives (mrt_small.hip); needs args.utab / args.vtab
 // host copy of a small scene in device order, from which the launcher derives the camera-dependent kernel arguments

@@ -94,7 +94,8 @@ inline float loose_factor()
   return f;
 }
 
-template <class BoundFn> inline void kd_order(size_t n, BoundFn bound, std::vector<uint32_t> &order)
+// *regular (optional): how many primitives at the head of the order are neither loose nor unbounded
+template <class BoundFn> inline void kd_order(size_t n, BoundFn bound, std::vector<uint32_t> &order, size_t *regular = nullptr)
 {
   order.clear();
   order.reserve(n);
@@ -123,16 +124,18 @@ template <class BoundFn> inline void kd_order(size_t n, BoundFn bound, std::vect
   }
   if (order.size() > 64) kd_split(order.data(), 0, order.size(), c.data());
   if (loose.size() > 64) kd_split(loose.data(), 0, loose.size(), c.data());
+  if (regular) *regular = order.size();
   order.insert(order.end(), loose.begin(), loose.end());
   order.insert(order.end(), unbounded.begin(), unbounded.end());
 }
 
 // MRT_ORDER=morton selects the Morton order (ablation); default: kd order
-template <class BoundFn> inline void primitive_order(size_t n, BoundFn bound, std::vector<uint32_t> &order)
+template <class BoundFn> inline void primitive_order(size_t n, BoundFn bound, std::vector<uint32_t> &order, size_t *regular = nullptr)
 {
   static const bool morton = [] { const char *e = getenv("MRT_ORDER"); return e && std::strcmp(e, "morton") == 0; }();
+  if (regular) *regular = n;
   if (morton) morton_order(n, bound, order);
-  else kd_order(n, bound, order);
+  else kd_order(n, bound, order, regular);
 }
 
 // bounding ball of each run of 64 balls (streams x,y,z,r of n floats) -> 4 streams of ceil(n/64) floats

@@ -197,7 +197,14 @@ __device__ __forceinline__ void render_small_body(uint32_t wh, float cone_ext_s,
   // u, v of the lane's pixels: tables hold float(i) / float(W) and float(i) / float(H) (uv_table_kernel); v is the
   // same for all of the wave's tiles, u is fetched one tile ahead
   const float *vtab_hot = utab_hot + uv_table_stride(W);
+#ifndef MRT_SMALL_UV
+#define MRT_SMALL_UV 0 // experiment: 1 = u, v by IEEE division in the wave instead of from the tables
+#endif
+#if MRT_SMALL_UV
+  const float v = float(grow) / float(H); // src/main.cu:137
+#else
   const float v = vtab_hot[grow < H ? grow : H - 1]; // rows beyond the frame are never written
+#endif
   using UV = typename VecOf<P>::f;
 
   // ---- cones around the tiles' rays, each padded by one pixel on every side (covers the 121-spp offsets): every
@@ -252,12 +259,17 @@ __device__ __forceinline__ void render_small_body(uint32_t wh, float cone_ext_s,
   for (int k = 1; k < TPW; ++k) primary_mask = j == k ? pmask[k] : primary_mask;
   const int col0 = tile_x * TW + tx * P;
   float u0[P];
+#if MRT_SMALL_UV
+#pragma unroll
+  for (int p = 0; p < P; ++p) u0[p] = float(col0 + p) / float(W); // src/main.cu:136
+#else
   {
     const UV uu = *reinterpret_cast<const UV *>(utab_hot + col0); // the table is padded to whole tiles
     const float *up = reinterpret_cast<const float *>(&uu);
 #pragma unroll
     for (int p = 0; p < P; ++p) u0[p] = up[p];
   }
+#endif
 
   float accr[P], accg[P], accb[P];
   int out_id[P];
