@@ -201,7 +201,10 @@ __device__ __forceinline__ bool triangle_may_be_hit(const DevScene &sc, const De
 }
 
 template <bool HIER, int P, bool MULTI, int NW, bool LSPLIT = false>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NW > 1 && !MULTI ? (LSPLIT ? MRT_CULL_LSPLIT_WAVES : MRT_CULL_TEAM_WAVES) : 1, 8)))
+#ifndef MRT_CULL_SINGLE_WAVES
+#define MRT_CULL_SINGLE_WAVES 1 // (experiment: 8 forces the one-wave-per-tile, one-sample kernel into 64 registers)
+#endif
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NW > 1 && !MULTI ? (LSPLIT ? MRT_CULL_LSPLIT_WAVES : MRT_CULL_TEAM_WAVES) : (!MULTI && P == 1 && HIER ? MRT_CULL_SINGLE_WAVES : 1), 8)))
 void render_cull_kernel(RenderArgs A)
 {
   const DevScene &sc = A.sc;
