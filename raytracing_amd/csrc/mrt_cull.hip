@@ -26,6 +26,7 @@
 #include "mrt_device.h"
 #include "mrt_cull_common.h"
 
+#include <algorithm>
 #include <cmath>
 #include <cstdlib>
 #include <type_traits>
@@ -79,12 +80,37 @@ template <> struct CVec<4> { typedef float f __attribute__((ext_vector_type(4)))
 #define MRT_REFINE_EPS 1e-4f // relative margin of the leaf refinement's edge functions (the exact test rounds at 6e-8)
 #endif
 enum { LOOSE_BLOCK_SHIFT = 6, LOOSE_BLOCK = 1 << LOOSE_BLOCK_SHIFT }; // the loose triangles' lists: one per block of 64 x 64 pixels
+// the tiles' bins (bin_primitives_kernel): counters start BIN_HEAD words into bin_cnt (word 0: the near list overflowed;
+// 1, 2: spheres / triangles in the near list), two per tile (spheres, triangles); bin_near holds BIN_NEAR_CAP of each
+enum { BIN_HEAD = 4, BIN_NEAR_CAP = 512 };
 #ifndef MRT_CULL_TEAM_WAVES
 #define MRT_CULL_TEAM_WAVES 1 // 7 fits the team kernels into 72 registers only by spilling to scratch (C4 3 % faster, 0.3 GB of extra writes per frame): left alone
 #endif
 #ifndef MRT_CULL_LSPLIT_WAVES
 #define MRT_CULL_LSPLIT_WAVES 6 // measured on the 64-light config: 6 waves with 23 registers spilled (1.163 ms) beat 5 waves with 8 spilled (1.184 ms): the kernel waits on memory, not on issue
 #endif
+// The cone around a tile's rays (tile column tile_x of TW-pixel-wide tiles, frame rows grow0 .. grow0 + 7), padded by one
+// pixel on every side: unit axis, half-angle, and the centre ray itself.  ONE definition, because two kernels must agree on
+// it to the bit: the tile kernel culls with it, and the binning kernel decides with it which tiles' lists a primitive
+// enters (bin_primitives_kernel).
+struct TileCone { float cax, cay, caz, cosT, sinT, dcx, dcy, dcz; };
+__device__ __forceinline__ TileCone make_tile_cone(const DevCamera &cam, int W, int H, float cone_ext, int tile_x, int TW, int grow0)
+{
+  TileCone t;
+  const float rw = fast_rcp(float(W)), rh = fast_rcp(float(H)); // bound arithmetic: approximate is fine
+  const float um = (float(tile_x * TW) + 0.5f * float(TW - 1)) * rw, vm = (float(grow0) + 3.5f) * rh;
+  t.dcx = ((cam.ux + um * cam.hx) + vm * cam.vx) - cam.ox;
+  t.dcy = ((cam.uy + um * cam.hy) + vm * cam.vy) - cam.oy;
+  t.dcz = ((cam.uz + um * cam.hz) + vm * cam.vz) - cam.oz;
+  const float inv = fast_rsq(dot3(t.dcx, t.dcy, t.dcz, t.dcx, t.dcy, t.dcz));
+  t.cax = t.dcx * inv; t.cay = t.dcy * inv; t.caz = t.dcz * inv;
+  t.sinT = cone_ext * inv * (1.0f + 1e-4f) + 1e-6f;
+  t.cosT = fast_sqrt(fmaxf(1.0f - t.sinT * t.sinT, 0.0f)) * (1.0f - 1e-5f) - 1e-6f;
+  // a cone of 90 degrees or more (or a NaN camera) cannot cull: cos = -1 makes every ball pass
+  if (!(t.sinT < 0.99f) || !(t.cosT > 0.0f)) { t.cosT = -1.0f; t.sinT = 0.0f; }
+  return t;
+}
+
 // ---- refinement of a triangle against a pyramid of primary rays (a tile, or a block of tiles) -------------------
 // What the pyramid looks like to the tests below: a cone around it (unit axis, half-angle) for the plane test, its
 // centre ray and half extents along the camera's horizontal / vertical for the screen-space edge functions.
@@ -280,22 +306,14 @@ void render_cull_kernel(RenderArgs A)
   float ehx, ehy, ehz, evx, evy, evz;      // half the padded tile's extent along the camera's horizontal / vertical
   constexpr int TRI_REFINE_MIN = 4;        // candidates in a leaf from which the per-triangle refinement runs
   {
+    const TileCone tc = make_tile_cone(cam, A.W, A.H, A.cone_ext, tile_x, TW, grow0);
+    cax = tc.cax; cay = tc.cay; caz = tc.caz; cosT = tc.cosT; sinT = tc.sinT;
+    dcx = tc.dcx; dcy = tc.dcy; dcz = tc.dcz;
     const float rw = fast_rcp(float(A.W)), rh = fast_rcp(float(A.H)); // bound arithmetic: approximate is fine
-    const float um = (float(tile_x * TW) + 0.5f * float(TW - 1)) * rw, vm = (float(grow0) + 3.5f) * rh;
-    cax = ((cam.ux + um * cam.hx) + vm * cam.vx) - cam.ox;
-    cay = ((cam.uy + um * cam.hy) + vm * cam.vy) - cam.oy;
-    caz = ((cam.uz + um * cam.hz) + vm * cam.vz) - cam.oz;
-    dcx = cax; dcy = cay; dcz = caz;
     cam_round = 2.0f * camera_rounding(cam); // a ray's and the centre ray's
     const float du = (0.5f * float(TW) + 0.51f) * rw * 1.001f, dv = 4.51f * rh * 1.001f; // pixels -1 .. 8P, -1 .. 8
     ehx = du * cam.hx; ehy = du * cam.hy; ehz = du * cam.hz;
     evx = dv * cam.vx; evy = dv * cam.vy; evz = dv * cam.vz;
-    const float inv = fast_rsq(dot3(cax, cay, caz, cax, cay, caz));
-    cax *= inv; cay *= inv; caz *= inv;
-    sinT = A.cone_ext * inv * (1.0f + 1e-4f) + 1e-6f;
-    cosT = fast_sqrt(fmaxf(1.0f - sinT * sinT, 0.0f)) * (1.0f - 1e-5f) - 1e-6f;
-    // a cone of 90 degrees or more (or a NaN camera) cannot cull: cos = -1 makes every ball pass
-    if (!(sinT < 0.99f) || !(cosT > 0.0f)) { cosT = -1.0f; sinT = 0.0f; }
   }
   // hierarchy tests against the cone: a ball of spheres / a ball of triangle bounds
   auto cone_vs_sphere_ball = [&](float x, float y, float z, float R) {
@@ -371,17 +389,17 @@ void render_cull_kernel(RenderArgs A)
 
     // ---- closest hit over spheres: src/main.cu:60-77, core/sphere.cuh:32-73, interval [0.01, inf] ----
     leaf_k = 0;
-    walk_hierarchy<HIER>(sc.sph_sclu, sc.nscs, sc.sph_clu, sc.ncs, lane, sphere_ball_in_reach, [&](int base) {
-      if (!MRT_TEAM_TAKES_LEAF()) return true;
-      const int i = base + lane;
+    // one batch of up to 64 candidate spheres, lane = sphere i (have: the lane has one).  binned: the cone test was made
+    // when the sphere entered this tile's list; base >= 0: the lanes' spheres are base + lane (a leaf of the hierarchy)
+    auto sphere_batch = [&](int i, bool have, int base, bool binned) {
       float cx = 0.0f, cy = 0.0f, cz = 0.0f, r = 0.0f;
       bool pass = false;
-      if (i < ns) {
+      if (have) {
         cx = sc.sph_cx[i]; cy = sc.sph_cy[i]; cz = sc.sph_cz[i]; r = sc.sph_r[i];
         const float wx = cx - cam.ox, wy = cy - cam.oy, wz = cz - cam.oz;
         const float L2 = dot3(wx, wy, wz, wx, wy, wz);
         const float reff = sphere_cull_radius(r * r, L2);
-        pass = ball_may_touch_cone(wx, wy, wz, reff, cax, cay, caz, cosT, sinT) &&
+        pass = (binned || ball_may_touch_cone(wx, wy, wz, reff, cax, cay, caz, cosT, sinT)) &&
                !(fast_sqrt(L2) * (1.0f - 1e-5f) - reff > reach_max);
       }
       unsigned long long mask = __ballot(pass);
@@ -393,7 +411,8 @@ void render_cull_kernel(RenderArgs A)
         const float scx = bcast(cx, j), scy = bcast(cy, j), scz = bcast(cz, j), sr = bcast(r, j);
         const float ocx = cam.ox - scx, ocy = cam.oy - scy, ocz = cam.oz - scz;
         const float c = dot3(ocx, ocy, ocz, ocx, ocy, ocz) - sr * sr;
-        const int obj = sc.sph_obj[base + j];
+        const int sj = base >= 0 ? base + j : __builtin_amdgcn_readlane(i, j); // lane j's sphere
+        const int obj = sc.sph_obj[sj];
 #pragma unroll
         for (int p = 0; p < P; ++p) {
           const float b = dot3(ocx, ocy, ocz, dx[p], dy[p], dz[p]);
@@ -402,15 +421,49 @@ void render_cull_kernel(RenderArgs A)
             float t;
             if (sphere_roots(aa[p], b, disc, 0.01f, MRT_INF, t)) {
               if (t < best_t[p] || (t == best_t[p] && t < MRT_INF && obj < best_obj[p])) {
-                best_t[p] = t; best_obj[p] = obj; best_prim[p] = base + j; moved = true;
+                best_t[p] = t; best_obj[p] = obj; best_prim[p] = sj; moved = true;
               }
             }
           }
         }
       }
       if (NW == 1 && __any(moved)) refresh_reach(); // (a team member only knows its own hits: it keeps +inf)
+    };
+    // PRIMARY RAYS FROM BINS.  The walk below asks, per tile, which primitives its cone may touch -- every tile walks the
+    // same upper levels, and a team repeats them in each member.  bin_primitives_kernel asks the other way round, once per
+    // frame: lane = primitive, which tiles' cones may touch its ball? -- and leaves a list per tile (the same cone, the
+    // same test: the list holds exactly the primitives the walk's leaves would have passed).  A tile whose lists fit
+    // takes its candidates from them; one whose lists overflowed (a horizon: thousands of sub-pixel triangles) walks.
+    const int gtile = (grow0 >> 3) * ((A.W + TW - 1) / TW) + tile_x; // the tile's number in the whole frame
+    bool binned_s = false, binned_t = false;
+    if constexpr (HIER && P == 1) {
+      if (A.bin_cnt && A.bin_cnt[0] == 0u) { // (word 0: the frame's near list overflowed -- nobody uses the bins)
+        const uint32_t cs = A.bin_cnt[BIN_HEAD + 2 * gtile], ct = A.bin_cnt[BIN_HEAD + 2 * gtile + 1];
+        binned_s = cs <= (uint32_t)A.bin_cap;
+        binned_t = ct <= (uint32_t)A.bin_cap;
+      }
+    }
+    leaf_k = 0;
+    if (binned_s) {
+      const uint32_t cs = A.bin_cnt[BIN_HEAD + 2 * gtile], cn = A.bin_cnt[1];
+      const uint32_t *list = A.bin_list + size_t(2 * gtile) * A.bin_cap;
+      for (uint32_t k0 = 0; k0 < cs; k0 += 64) {
+        if (!MRT_TEAM_TAKES_LEAF()) continue;
+        const bool have = k0 + lane < cs;
+        sphere_batch(have ? int(list[k0 + lane]) : 0, have, -1, true);
+      }
+      for (uint32_t k0 = 0; k0 < cn; k0 += 64) { // spheres around or behind the camera: every tile's business
+        if (!MRT_TEAM_TAKES_LEAF()) continue;
+        const bool have = k0 + lane < cn;
+        sphere_batch(have ? int(A.bin_near[k0 + lane]) : 0, have, -1, false);
+      }
+    } else {
+    walk_hierarchy<HIER>(sc.sph_sclu, sc.nscs, sc.sph_clu, sc.ncs, lane, sphere_ball_in_reach, [&](int base) {
+      if (!MRT_TEAM_TAKES_LEAF()) return true;
+      sphere_batch(base + lane, base + lane < ns, base, false);
       return true;
     });
+    }
 
     // ---- closest hit over triangles: core/triangle.cuh:77-103 ----
     // one batch of up to 64 candidate triangles, lane = triangle i (pass: the lane has one): refinement when the
@@ -462,6 +515,28 @@ void render_cull_kernel(RenderArgs A)
     // the reference's edge planes accept, whose bounding balls every tile's cone touches -- come from a list per
     // 64 x 64-pixel block instead (bin_loose_kernel, once per frame): the tile refines only what its block kept.
     const bool use_lists = HIER && A.loose_cnt != nullptr; // wave-uniform
+    if (binned_t) {
+      // the regular triangles from the tile's list (the loose ones follow from their block's list, or all of them)
+      const uint32_t ct = A.bin_cnt[BIN_HEAD + 2 * gtile + 1], cn = A.bin_cnt[2];
+      const uint32_t *list = A.bin_list + size_t(2 * gtile + 1) * A.bin_cap;
+      for (uint32_t k0 = 0; k0 < ct; k0 += 64) {
+        if (!MRT_TEAM_TAKES_LEAF()) continue;
+        const bool have = k0 + lane < ct;
+        triangle_batch(have ? int(list[k0 + lane]) : 0, have, -1);
+      }
+      for (uint32_t k0 = 0; k0 < cn; k0 += 64) { // triangles whose bound reaches round the camera
+        if (!MRT_TEAM_TAKES_LEAF()) continue;
+        const bool have = k0 + lane < cn;
+        const int i = have ? int(A.bin_near[BIN_NEAR_CAP + k0 + lane]) : 0;
+        triangle_batch(i, have && tri_ball_in_reach(sc.tri_bx[i], sc.tri_by[i], sc.tri_bz[i], sc.tri_br[i]), -1);
+      }
+      if (!use_lists) // no block lists for the loose triangles: their clusters are walked
+        for (int base = A.bin_nct_regular * 64; base < nt; base += 64) {
+          if (!MRT_TEAM_TAKES_LEAF()) continue;
+          const int i = base + lane;
+          triangle_batch(i, i < nt && tri_ball_in_reach(sc.tri_bx[i], sc.tri_by[i], sc.tri_bz[i], sc.tri_br[i]), base);
+        }
+    } else {
     walk_hierarchy<HIER>(sc.tri_sclu, sc.nsct, sc.tri_clu, sc.nct, lane, tri_ball_in_reach, [&](int base) {
       if (!MRT_TEAM_TAKES_LEAF()) return true;
       const int i = base + lane;
@@ -470,6 +545,7 @@ void render_cull_kernel(RenderArgs A)
       triangle_batch(i, pass, base);
       return true;
     }, use_lists ? A.loose_nct_walk : -1);
+    }
     if constexpr (HIER) {
       if (use_lists) {
         const int blk = (grow0 >> LOOSE_BLOCK_SHIFT) * A.loose_bx + ((tile_x * TW) >> LOOSE_BLOCK_SHIFT);
@@ -1071,11 +1147,179 @@ static bool loose_lists_apply(const RenderArgs &A)
   const long nloose = (long)A.sc.nt - (long)A.sc.nct_regular * 64;
   return on && A.sc.nct > 1 && A.sc.nct_regular < A.sc.nct && nloose >= least && nloose <= 65536 && A.spp == 1;
 }
-size_t loose_scratch_bytes(const RenderArgs &A)
+static size_t loose_bytes(const RenderArgs &A)
 {
   if (!loose_lists_apply(A)) return 0;
   const size_t blocks = size_t((A.W + LOOSE_BLOCK - 1) / LOOSE_BLOCK) * size_t((A.H + LOOSE_BLOCK - 1) / LOOSE_BLOCK);
-  return ((blocks * 4 + 255) / 256) * 256 + blocks * MRT_LOOSE_CAP * 2;
+  return (((blocks * 4 + 255) / 256) * 256 + blocks * MRT_LOOSE_CAP * 2 + 255) / 256 * 256;
+}
+
+// ---- the tiles' bins: which tiles can a primitive's bound be seen from? ---------------------------------------------
+// lane = primitive (spheres first, then the regular triangles).  Its bounding ball, inflated exactly as the tile kernel
+// inflates it, projects onto a rectangle of the image (closed form: the two tangent planes through the camera that are
+// parallel to the image's vertical give the extent in u, and likewise in v); over that rectangle's tiles, plus one tile
+// all round -- a tile's cone is the circle around its padded square and reaches up to four pixels past it -- the lane
+// runs the tile kernel's own test, the tile's own cone (make_tile_cone) against the ball, and appends itself to the
+// lists of the tiles that pass.  So a tile's list holds exactly the primitives its walk would have handed to the exact
+// tests.  Balls that reach round or behind the camera (no rectangle), balls without a finite bound and rectangles of
+// more than BIN_MAX_RECT tiles go to the frame's near list, which every tile takes; if that overflows, word 0 of the
+// counters says so and the frame is rendered by the walk.  Lists that outgrow bin_cap keep counting: their tiles walk.
+struct BinCamera {
+  float hx, hy, hz, vx, vy, vz, nx, ny, nz; // unit vectors along the image's horizontal and vertical, and into the scene
+  float bh, bv, bn;                         // the image's corner (u = v = 0) in that frame; bn > 0
+  float lh, lv;                             // lengths of the horizontal and vertical edges
+};
+enum { BIN_MAX_RECT = 4096, BIN_DIRECT = 4, BIN_QUEUE_CAP = 1 << 18 };
+// the ball of primitive g (spheres first, then triangles) as the tile kernel tests it against a cone: centre - origin, radius
+__device__ __forceinline__ void bin_ball(const DevScene &sc, const DevCamera &cam, int g, float &wx, float &wy, float &wz, float &reff)
+{
+  if (g < sc.ns) {
+    const float r = sc.sph_r[g];
+    wx = sc.sph_cx[g] - cam.ox; wy = sc.sph_cy[g] - cam.oy; wz = sc.sph_cz[g] - cam.oz;
+    reff = sphere_cull_radius(r * r, dot3(wx, wy, wz, wx, wy, wz)); // as sphere_batch
+  } else {
+    const int i = g - sc.ns;
+    wx = sc.tri_bx[i] - cam.ox; wy = sc.tri_by[i] - cam.oy; wz = sc.tri_bz[i] - cam.oz;
+    reff = sc.tri_br[i] * CULL_REL + CULL_ABS;                      // as cone_vs_tri_ball
+  }
+}
+// primitive g against tile (tx, ty): the tile kernel's own test; a pass appends g to the tile's list of its type
+__device__ __forceinline__ void bin_try_tile(const RenderArgs &A, int TW, int tiles_x, int g, float wx, float wy, float wz, float reff,
+                                             int tx, int ty, uint32_t *__restrict__ cnt, uint32_t *__restrict__ list)
+{
+  const TileCone t = make_tile_cone(A.cam, A.W, A.H, A.cone_ext, tx, TW, ty * 8);
+  if (!ball_may_touch_cone(wx, wy, wz, reff, t.cax, t.cay, t.caz, t.cosT, t.sinT)) return;
+  const bool tri = g >= A.sc.ns;
+  const int slot = 2 * (ty * tiles_x + tx) + (tri ? 1 : 0);
+  const uint32_t pos = atomicAdd(&cnt[BIN_HEAD + slot], 1u);
+  if (pos < (uint32_t)A.bin_cap) list[size_t(slot) * A.bin_cap + pos] = (uint32_t)(tri ? g - A.sc.ns : g);
+}
+
+// Pass 1, lane = primitive: the rectangle; small ones (up to BIN_DIRECT tiles: the million sub-pixel triangles of a
+// terrain) are binned on the spot, larger ones are cut into blocks of 8 x 8 tiles and queued for pass 2 -- a handful of
+// large spheres would otherwise keep a few lanes looping over thousands of tiles while the GPU idles.
+__global__ __launch_bounds__(256) void bin_primitives_kernel(RenderArgs A, BinCamera C, int TW, uint32_t *__restrict__ cnt,
+                                                             uint32_t *__restrict__ list, uint32_t *__restrict__ near_list,
+                                                             uint2 *__restrict__ queue)
+{
+  const DevScene &sc = A.sc;
+  const int g = blockIdx.x * 256 + threadIdx.x;
+  const int ns = sc.ns, ntr = min(sc.nt, A.bin_nct_regular * 64);
+  const bool live = g < ns + ntr; // (lanes past the last primitive stay: the wave shares the larger rectangles out)
+  const bool tri = g >= ns;
+  float wx = 0.0f, wy = 0.0f, wz = 0.0f, reff = 0.0f;
+  if (live) bin_ball(sc, A.cam, g, wx, wy, wz, reff);
+  const int tiles_x = (A.W + TW - 1) / TW, tiles_y = (A.H + 7) >> 3;
+  int tx0 = 0, tx1 = -1, ty0 = 0, ty1 = -1;
+  bool near = live;
+  if (live) {
+    const float X = dot3(wx, wy, wz, C.hx, C.hy, C.hz), Y = dot3(wx, wy, wz, C.vx, C.vy, C.vz), Z = dot3(wx, wy, wz, C.nx, C.ny, C.nz);
+    const float L1 = norm1(wx, wy, wz);
+    const float R = reff * 1.02f + 1e-5f * L1 + 1e-6f; // the test's slack (CULL_LEN_SLACK of |w|_1) and this block's own rounding
+    if (Z > R * 1.01f + 1e-5f * L1 && R < 3.0e37f) {   // the ball lies in front of the camera plane, clear of it (NaN: near)
+      const float den = Z * Z - R * R;                 // > 0
+      const float sx = R * fast_sqrt(fmaxf(X * X + den, 0.0f)), sy = R * fast_sqrt(fmaxf(Y * Y + den, 0.0f));
+      const float iden = fast_rcp(den);
+      // tangents of the extreme directions, then u = (x bn - bh) / lh and v likewise
+      const float xlo = (X * Z - sx) * iden, xhi = (X * Z + sx) * iden, ylo = (Y * Z - sy) * iden, yhi = (Y * Z + sy) * iden;
+      const float ulo = (xlo * C.bn - C.bh) / C.lh, uhi = (xhi * C.bn - C.bh) / C.lh;
+      const float vlo = (ylo * C.bn - C.bv) / C.lv, vhi = (yhi * C.bn - C.bv) / C.lv;
+      // pixels, padded by what a tile's cone reaches beyond the tile (it is the circle around the padded square of 10 x 10
+      // pixels, radius 7.1, the tile itself reaches 4 from its centre: 3.1), a pixel and 1e-4 of the frame
+      const float pw = 1e-4f * float(A.W) + 4.2f, ph = 1e-4f * float(A.H) + 4.2f;
+      const float c0 = ulo * float(A.W) - pw, c1 = uhi * float(A.W) + pw, r0 = vlo * float(A.H) - ph, r1 = vhi * float(A.H) + ph;
+      if (c0 == c0 && c1 == c1 && r0 == r0 && r1 == r1) { // no NaN
+        const float big = 1.0e7f;
+        tx0 = int(floorf(fminf(fmaxf(c0, -big), big) / float(TW))); tx1 = int(floorf(fminf(fmaxf(c1, -big), big) / float(TW)));
+        ty0 = int(floorf(fminf(fmaxf(r0, -big), big) * 0.125f));   ty1 = int(floorf(fminf(fmaxf(r1, -big), big) * 0.125f));
+        tx0 = max(tx0, 0); ty0 = max(ty0, 0); tx1 = min(tx1, tiles_x - 1); ty1 = min(ty1, tiles_y - 1);
+        near = (long)(tx1 - tx0 + 1) * (long)(ty1 - ty0 + 1) > BIN_MAX_RECT; // (an empty rectangle: off the frame, nothing to do)
+      }
+    }
+  }
+  if (near) {
+    const uint32_t pos = atomicAdd(&cnt[tri ? 2 : 1], 1u);
+    if (pos < BIN_NEAR_CAP) near_list[(tri ? BIN_NEAR_CAP : 0) + pos] = (uint32_t)(tri ? g - ns : g);
+    else cnt[0] = 1u; // the frame falls back to the walk
+  }
+  const int rw = tx1 - tx0 + 1, rh = ty1 - ty0 + 1;
+  const int ntile = (near || rw <= 0 || rh <= 0) ? 0 : rw * rh;
+  if (ntile > 0 && ntile <= BIN_DIRECT) { // a few tiles: on the spot
+    for (int ty = ty0; ty <= ty1; ++ty)
+      for (int tx = tx0; tx <= tx1; ++tx) bin_try_tile(A, TW, tiles_x, g, wx, wy, wz, reff, tx, ty, cnt, list);
+  }
+  // (sharing a lane's rectangle out over its own wave's 64 lanes instead of queueing it was slower on 10k spheres, 0.40
+  // against 0.36 ms: 157 waves is all that pass 1 has there, pass 2 spreads the same work over the chip)
+  if (ntile > BIN_DIRECT) { // larger: cut into blocks of 8 x 8 tiles for pass 2
+    const int bx0 = tx0 >> 3, bx1 = tx1 >> 3, by0 = ty0 >> 3, by1 = ty1 >> 3;
+    const uint32_t nb = uint32_t((bx1 - bx0 + 1) * (by1 - by0 + 1));
+    const uint32_t pos = atomicAdd(&cnt[3], nb);
+    if (pos + nb > BIN_QUEUE_CAP) { cnt[0] = 1u; }
+    else {
+      uint32_t k = pos;
+      for (int by = by0; by <= by1; ++by)
+        for (int bx = bx0; bx <= bx1; ++bx) queue[k++] = make_uint2((uint32_t)g, (uint32_t)bx | ((uint32_t)by << 16));
+    }
+  }
+}
+
+// Pass 2, wave = (primitive, block of 8 x 8 tiles) from the queue, lane = tile.  A fixed grid of waves strides over the
+// queue (its length is only known on the device).
+__global__ __launch_bounds__(256) void bin_blocks_kernel(RenderArgs A, int TW, uint32_t *__restrict__ cnt, uint32_t *__restrict__ list,
+                                                         const uint2 *__restrict__ queue)
+{
+  const int lane = threadIdx.x & 63;
+  const uint32_t nq = min(cnt[3], (uint32_t)BIN_QUEUE_CAP), nwaves = gridDim.x * 4u;
+  const int tiles_x = (A.W + TW - 1) / TW, tiles_y = (A.H + 7) >> 3;
+  for (uint32_t q = blockIdx.x * 4u + (threadIdx.x >> 6); q < nq; q += nwaves) {
+    const uint2 e = queue[q];
+    const int g = int(e.x), tx = int(e.y & 0xffffu) * 8 + (lane & 7), ty = int(e.y >> 16) * 8 + (lane >> 3);
+    float wx, wy, wz, reff;
+    bin_ball(A.sc, A.cam, g, wx, wy, wz, reff);
+    if (tx < tiles_x && ty < tiles_y) bin_try_tile(A, TW, tiles_x, g, wx, wy, wz, reff, tx, ty, cnt, list);
+  }
+}
+
+// entries per tile and primitive type: two batches
+#ifndef MRT_BIN_CAP
+#define MRT_BIN_CAP 128
+#endif
+// Bins apply to scenes with a hierarchy to walk, one pixel per lane, and a camera whose image is a rectangle (horizontal
+// and vertical edges perpendicular: what rt::Viewport makes; anything else walks).  MRT_BINS=0 switches them off.
+static bool bins_apply(const RenderArgs &A, BinCamera *out)
+{
+  static const bool on = !(getenv("MRT_BINS") && atoi(getenv("MRT_BINS")) == 0);
+  // (below a few thousand primitives the walk is a handful of steps per tile and not worth two more launches; with
+  // more primitives than tiles the lists cost more than the walks they save: 1M triangles at 4K 2.45 -> 2.69 ms
+  // with them -- a tile there spends its time on the exact tests, which the lists do not change -- 10k spheres
+  // 0.437 -> 0.368 ms.  MRT_BINS=2 lifts the upper limit for measurements.)
+  static const bool any = getenv("MRT_BINS") && atoi(getenv("MRT_BINS")) == 2;
+  const long nprim = (long)A.sc.ns + A.sc.nt, ntile = (long)((A.W + 7) / 8) * ((A.H + 7) / 8);
+  if (!on || nprim < 2048 || (nprim > ntile && !any)) return false;
+  const double h[3] = {A.cam.hx, A.cam.hy, A.cam.hz}, v[3] = {A.cam.vx, A.cam.vy, A.cam.vz};
+  const double b[3] = {(double)A.cam.ux - A.cam.ox, (double)A.cam.uy - A.cam.oy, (double)A.cam.uz - A.cam.oz};
+  auto dot = [](const double *x, const double *y) { return x[0] * y[0] + x[1] * y[1] + x[2] * y[2]; };
+  const double lh = std::sqrt(dot(h, h)), lv = std::sqrt(dot(v, v));
+  if (!(lh > 1e-30) || !(lv > 1e-30) || !std::isfinite(lh) || !std::isfinite(lv)) return false;
+  const double hu[3] = {h[0] / lh, h[1] / lh, h[2] / lh}, vu[3] = {v[0] / lv, v[1] / lv, v[2] / lv};
+  if (!(std::fabs(dot(hu, vu)) < 1e-4)) return false;
+  double n[3] = {hu[1] * vu[2] - hu[2] * vu[1], hu[2] * vu[0] - hu[0] * vu[2], hu[0] * vu[1] - hu[1] * vu[0]};
+  double bn = dot(b, n);
+  if (bn < 0) { bn = -bn; n[0] = -n[0]; n[1] = -n[1]; n[2] = -n[2]; }
+  if (!(bn > 1e-6 * (std::fabs(dot(b, hu)) + std::fabs(dot(b, vu)) + lh + lv)) || !std::isfinite(bn)) return false;
+  if (out) {
+    out->hx = (float)hu[0]; out->hy = (float)hu[1]; out->hz = (float)hu[2];
+    out->vx = (float)vu[0]; out->vy = (float)vu[1]; out->vz = (float)vu[2];
+    out->nx = (float)n[0]; out->ny = (float)n[1]; out->nz = (float)n[2];
+    out->bh = (float)dot(b, hu); out->bv = (float)dot(b, vu); out->bn = (float)bn; out->lh = (float)lh; out->lv = (float)lv;
+  }
+  return true;
+}
+static size_t bins_bytes(const RenderArgs &A)
+{
+  if (!bins_apply(A, nullptr)) return 0;
+  const size_t tiles = size_t((A.W + 7) / 8) * size_t((A.H + 7) / 8);
+  return ((BIN_HEAD + 2 * tiles) * 4 + 255) / 256 * 256 + 2 * BIN_NEAR_CAP * 4 + (size_t)BIN_QUEUE_CAP * 8 + 2 * tiles * MRT_BIN_CAP * 4;
 }
 
 // Waves per tile for a scene (render_cull_kernel's NW and LSPLIT).  A team pays for itself when single tiles are long
@@ -1119,6 +1363,27 @@ static hipError_t launch_cull(RenderArgs &A, hipStream_t stream)
            ((uintptr_t)A.t & align) == 0;
   const int tiles_x = (A.W + 8 * P - 1) / (8 * P), tiles_y = (A.local_rows + 7) / 8;
   if (tiles_x == 0 || tiles_y == 0) return hipSuccess;
+  if constexpr (HIER && P == 1) {
+    BinCamera C;
+    if (A.bin_cnt && bins_apply(A, &C)) {
+      const size_t tiles = size_t((A.W + 7) / 8) * size_t((A.H + 7) / 8);
+      hipError_t e = hipMemsetAsync((void *)A.bin_cnt, 0, (BIN_HEAD + 2 * tiles) * 4, stream);
+      if (e != hipSuccess) return e;
+      const long nprim = (long)A.sc.ns + std::min<long>(A.sc.nt, (long)A.bin_nct_regular * 64);
+      uint2 *queue = (uint2 *)(A.bin_near + 2 * BIN_NEAR_CAP);
+      if (nprim > 0) {
+        hipLaunchKernelGGL(bin_primitives_kernel, dim3((unsigned)((nprim + 255) / 256)), dim3(256), 0, stream, A, C, 8,
+                           (uint32_t *)A.bin_cnt, (uint32_t *)A.bin_list, (uint32_t *)A.bin_near, queue);
+        hipLaunchKernelGGL(bin_blocks_kernel, dim3(2048), dim3(256), 0, stream, A, 8, (uint32_t *)A.bin_cnt, (uint32_t *)A.bin_list,
+                           (const uint2 *)queue);
+      }
+      if ((e = hipGetLastError()) != hipSuccess) return e;
+    } else {
+      A.bin_cnt = nullptr;
+    }
+  } else {
+    A.bin_cnt = nullptr;
+  }
   // XCD-aware tile order for scenes with a hierarchy (their leaves are what neighbouring tiles share); MRT_CULL_XCD=0: rows
   // (MRT_CULL_XCD = n: blocks of 2^n x 2^n tiles, whatever the scene; 0: rows.)  By default for scenes that do not fit an
   // L2 (from 100 000 primitives on): the 1M-triangle terrain 2.61 -> 2.41 ms; scenes that do fit lose 1-3 % to the
@@ -1157,12 +1422,24 @@ static hipError_t launch_cull(RenderArgs &A, hipStream_t stream)
   return hipGetLastError();
 }
 
+size_t loose_scratch_bytes(const RenderArgs &A) { return loose_bytes(A) + bins_bytes(A); }
+
 hipError_t launch_render_cull(const RenderArgs &in, hipStream_t stream) { return launch_render_cull(in, nullptr, stream); }
 
 hipError_t launch_render_cull(const RenderArgs &in, void *loose_scratch, hipStream_t stream)
 {
   RenderArgs A = in;
   A.loose_list = nullptr; A.loose_cnt = nullptr;
+  A.bin_cnt = nullptr; A.bin_list = nullptr; A.bin_near = nullptr;
+  if (loose_scratch && bins_bytes(A)) { // the tiles' bins sit behind the loose triangles' lists; filled by launch_cull<true, 1>
+    const size_t tiles = size_t((A.W + 7) / 8) * size_t((A.H + 7) / 8);
+    char *b = (char *)loose_scratch + loose_bytes(A);
+    A.bin_cnt = (const uint32_t *)b;
+    A.bin_near = (const uint32_t *)(b + ((BIN_HEAD + 2 * tiles) * 4 + 255) / 256 * 256);
+    A.bin_list = A.bin_near + 2 * BIN_NEAR_CAP + 2 * (size_t)BIN_QUEUE_CAP; // (the queue of the two binning passes sits in between)
+    A.bin_cap = MRT_BIN_CAP;
+    A.bin_nct_regular = A.sc.nct_regular;
+  }
   if (loose_scratch && loose_lists_apply(A)) {
     const int bx = (A.W + LOOSE_BLOCK - 1) / LOOSE_BLOCK, by = (A.H + LOOSE_BLOCK - 1) / LOOSE_BLOCK;
     const size_t blocks = size_t(bx) * by;

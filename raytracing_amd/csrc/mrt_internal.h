@@ -104,6 +104,15 @@ struct RenderArgs {
   const uint32_t *loose_cnt;
   int32_t loose_bx, loose_cap;          // blocks per row of blocks; entries per block
   int32_t loose_nct_walk, loose_nsct_walk; // clusters / super-clusters the hierarchy walk still covers
+  // cull kernel, primary rays: per-tile lists of the primitives whose bound the tile's cone may touch (mrt_cull.hip,
+  // bin_primitives_kernel).  bin_cnt: BIN_HEAD control words, then two counters per tile of the whole frame (spheres,
+  // triangles); bin_list: bin_cap entries per counter; bin_near: primitives around the camera, for every tile.
+  // Null: no bins, every tile walks the hierarchy.
+  const uint32_t *bin_cnt;
+  const uint32_t *bin_list;
+  const uint32_t *bin_near;
+  int32_t bin_cap;
+  int32_t bin_nct_regular;              // triangle clusters the bins cover (the loose ones behind them are not binned)
 };
 
 hipError_t launch_render_cull(const RenderArgs &args, hipStream_t stream);

@@ -22,7 +22,9 @@ def _render(ctx, torch, cam, W, H, static, spp=1, stream=None, **part):
     ctx.render_device(cam, W, H, rgb.data_ptr(), id_ptr=ids.data_ptr(), t_ptr=tt.data_ptr(), stats_ptr=cnt.data_ptr(),
                       stream=st, spp=spp, static=static, **part)
     torch.cuda.synchronize()
-    return rgb.cpu().numpy(), ids.cpu().numpy(), tt.cpu().numpy(), cnt.cpu().numpy()[:6]
+    # counters 0..3: primary rays, shadow rays, hit pixels, occluded rays.  (4, 5 count exact tests and batches of candidates:
+    # diagnostics of HOW the frame was culled, and the allocation-free entry point culls without the per-frame lists.)
+    return rgb.cpu().numpy(), ids.cpu().numpy(), tt.cpu().numpy(), cnt.cpu().numpy()[:4]
 
 
 def _same(a, b, what):
