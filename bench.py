@@ -450,10 +450,13 @@ def measure(env, name, headline):
         ach_gbs = alg_bytes / (kern_ms * 1e-3) / 1e9
         small = flat.num_spheres + flat.num_triangles <= 64
         if max_depth > 0:
-            kernel_name = "render_bounce_small_kernel" if small else "render_bounce_kernel"
-            kernel_desc = ("render_bounce_small_kernel: 8x8-pixel tiles, every lane walks its pixel's samples and bounce "
-                           "chains as its own state machine (XORWOW stream per pixel); per-tile candidates for primary "
-                           "rays, shadow bundles, brute force further down the chains")
+            pipe = small and os.environ.get("MRT_BOUNCE_PIPE", "1") != "0"
+            kernel_name = ("render_bounce_pipe_kernel" if pipe else "render_bounce_small_kernel") if small else "render_bounce_kernel"
+            kernel_desc = (kernel_name + ": 8x8-pixel tiles, every lane walks its pixel's samples and bounce chains as its "
+                           "own state machine (XORWOW stream per pixel); per-tile candidates for primary rays, shadow "
+                           "bundles, brute force further down the chains"
+                           + ("; two waves per tile: one traces (closest hits, bounces, draws), one shades (shadow rays, "
+                              "lights, level stack), an LDS ring between them" if pipe else ""))
         elif args.brute_force:
             kernel_name, kernel_desc = "render_kernel", "render_kernel (brute force: every ray x every primitive)"
         elif small:

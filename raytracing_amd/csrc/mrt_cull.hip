@@ -87,7 +87,7 @@ enum { BIN_HEAD = 4, BIN_NEAR_CAP = 512 };
 #define MRT_CULL_TEAM_WAVES 1 // 7 fits the team kernels into 72 registers only by spilling to scratch (C4 3 % faster, 0.3 GB of extra writes per frame): left alone
 #endif
 #ifndef MRT_CULL_LSPLIT_WAVES
-#define MRT_CULL_LSPLIT_WAVES 6 // measured on the 64-light config: 6 waves with 23 registers spilled (1.163 ms) beat 5 waves with 8 spilled (1.184 ms): the kernel waits on memory, not on issue
+#define MRT_CULL_LSPLIT_WAVES 7 // measured on the 64-light config with the pass's results in LDS (tm_pre): 7 waves (72 registers, 5 spilled outside the light loop) 1.042 ms, 6 waves (74, none spilled) 1.088 ms, 8 waves (64, 15 spilled) see DESIGN.md; before, with the results in pair lanes' registers, 6 waves spilled 23 of them inside the loop: 1.163 ms
 #endif
 // The cone around a tile's rays (tile column tile_x of TW-pixel-wide tiles, frame rows grow0 .. grow0 + 7), padded by one
 // pixel on every side: unit axis, half-angle, and the centre ray itself.  ONE definition, because two kernels must agree on
@@ -250,8 +250,13 @@ void render_cull_kernel(RenderArgs A)
 #define MRT_CULL_LCH 16
 #endif
   constexpr int LCH = MRT_CULL_LCH;                            // lights per fold
+  constexpr int PRE_LPP = 16;                                  // lights per precompute pass (LDS slots per member)
   __shared__ float tm_c[LSPLIT ? 3 * LCH * 64 : 1];            // a light's contribution, [channel][light % LCH][lane]
   __shared__ unsigned long long tm_lit[LSPLIT ? LCH : 1];      // lanes the light contributes to
+  // what a member's precompute_pass leaves for its next lights, [member][light of the pass][field] (the member's own
+  // wave writes and reads it: no barrier).  In pair lanes' registers these 15 values were spilled to scratch and
+  // reloaded for every light (96 B per lane, 0.37 GB of scratch writes per C5 frame)
+  __shared__ float tm_pre[LSPLIT ? NWS * PRE_LPP * 16 : 1];
   const int member = NW > 1 ? wave : 0;
 
   // 2-D grid: blockIdx.y = tile row, blockIdx.x*4 + wave = tile column (both wave-uniform, so the strip
@@ -702,18 +707,25 @@ void render_cull_kernel(RenderArgs A)
           }
         fEa = wave_max(ea); fE1 = wave_max(e1); fE2 = wave_max(e2);
       }
-      // per (light, cluster) pair of the current chunk, in the pair's lane
-      float pDx = 0.0f, pDy = 0.0f, pDz = 0.0f, pDD = 0.0f, pnx = 0.0f, pny = 0.0f, pnz = 0.0f, psw = MRT_INF;
-      float plx = 0.0f, ply = 0.0f, plz = 0.0f, plr = 0.0f, plg = 0.0f, plb = 0.0f; // the pair's light: position / direction, colour
-      int plk = 0;                                                                     // ... and kind
+      // Which member takes which light: round robin.  (Member 0 also folds every light's contribution into the pixels;
+      // dealing it half a share -- one of seven lights in a row, the others two each -- was slower, 1.17 against 1.04 ms
+      // on 64 lights: a chunk of 16 lights ends at a barrier and takes as long as the member with most lights in it.)
+      auto light_owner = [](int li) { return li % NWS; };
+      auto light_place = [](int li) { return li / NWS; };
+      auto member_light = [](int m, int n) { return m + NWS * n; };
+      // lights per pass: what fits the wave's lanes, at most PRE_LPP (the LDS slots of a member)
+      const int pre_lpp = (64 >> pre_shift) < PRE_LPP ? (64 >> pre_shift) : PRE_LPP;
+      float *const my_pre = tm_pre + (LSPLIT ? member * PRE_LPP * 16 : 0);
       unsigned long long pre_mask = 0; // bit = lane = pair: the cluster may be touched by the light's bundle
       auto precompute_pass = [&](int li0) {
-        // this member's lights from li0 on: li0 + NWS j, j = 0 .. (64 >> pre_shift) - 1
+        // this member's lights from its li0-th on, j = 0 .. pre_lpp - 1
         const int j = lane >> pre_shift, c = lane & ((1 << pre_shift) - 1);
-        const int li = li0 + NWS * j;
-        const bool okl = li < sc.nl;
+        const int li = member_light(member, li0 + j);
+        const bool okl = j < pre_lpp && li < sc.nl;
         Bundle Bl = B;
         Bl.point = false; Bl.Dx = 0.0f; Bl.Dy = 0.0f; Bl.Dz = 0.0f;
+        float plx = 0.0f, ply = 0.0f, plz = 0.0f, plr = 0.0f, plg = 0.0f, plb = 0.0f; // the pair's light: position / direction, colour
+        int plk = 0;                                                                     // ... and kind
         if (okl) {
           const float lvx = sc.light_vec[3 * li], lvy = sc.light_vec[3 * li + 1], lvz = sc.light_vec[3 * li + 2];
           plx = lvx; ply = lvy; plz = lvz; plk = sc.light_kind[li];
@@ -737,19 +749,34 @@ void render_cull_kernel(RenderArgs A)
           }
         }
         bool pass = false;
+        // (the cluster's number through an opaque copy: otherwise the eight 64-bit per-lane addresses below are hoisted
+        // out of the light loop and kept -- in scratch -- across it)
+        unsigned cu = (unsigned)c;
+        asm volatile("" : "+v"(cu));
         if (okl && c < ncl) {
           if (c < sc.ncs) {
-            const float x = sc.sph_clu[c], y = sc.sph_clu[sc.ncs + c], z = sc.sph_clu[2 * sc.ncs + c], R = sc.sph_clu[3 * sc.ncs + c];
+            const unsigned n = (unsigned)sc.ncs;
+            const float x = sc.sph_clu[cu], y = sc.sph_clu[n + cu], z = sc.sph_clu[2u * n + cu], R = sc.sph_clu[3u * n + cu];
             const float wx = x - B.mx, wy = y - B.my, wz = z - B.mz;
             const float Lm = fast_sqrt(dot3(wx, wy, wz, wx, wy, wz)) * CULL_REL + B.rho + R;
             pass = bundle_may_touch(Bl, x, y, z, cluster_cull_radius(R, Lm));
           } else {
-            const int k = c - sc.ncs;
-            pass = bundle_may_touch(Bl, sc.tri_clu[k], sc.tri_clu[sc.nct + k], sc.tri_clu[2 * sc.nct + k], sc.tri_clu[3 * sc.nct + k]);
+            const unsigned k = cu - (unsigned)sc.ncs, n = (unsigned)sc.nct;
+            pass = bundle_may_touch(Bl, sc.tri_clu[k], sc.tri_clu[n + k], sc.tri_clu[2u * n + k], sc.tri_clu[3u * n + k]);
           }
         }
-        pDx = Bl.Dx; pDy = Bl.Dy; pDz = Bl.Dz; pDD = Bl.DD; pnx = Bl.snx; pny = Bl.sny; pnz = Bl.snz; psw = Bl.sw;
         pre_mask = __ballot(pass);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); // (the previous pass's slots have been read)
+        if (okl && c == 0) { // the light's first pair lane leaves what every pair of the light computed
+          float4 *q = reinterpret_cast<float4 *>(my_pre + j * 16);
+          q[0] = make_float4(Bl.Dx, Bl.Dy, Bl.Dz, Bl.DD);
+          q[1] = make_float4(Bl.snx, Bl.sny, Bl.snz, Bl.sw);
+          q[2] = make_float4(plx, ply, plz, __int_as_float(plk));
+          q[3] = make_float4(plr, plg, plb, 0.0f);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
       };
       auto shade_light = [&](auto point_tag, int li, float lvx, float lvy, float lvz, int pj) {
         constexpr bool POINT = decltype(point_tag)::value;
@@ -778,10 +805,15 @@ void render_cull_kernel(RenderArgs A)
         }
         unsigned long long pre_bits = 0; // clusters the light's bundle may touch (spheres first), when pre-computed
         if constexpr (LSPLIT) {
-          const int src = (pj << pre_shift) & 63; // the light's first pair lane holds what every pair of the light computed
-          B.Dx = bcast(pDx, src); B.Dy = bcast(pDy, src); B.Dz = bcast(pDz, src); B.DD = bcast(pDD, src);
-          B.snx = bcast(pnx, src); B.sny = bcast(pny, src); B.snz = bcast(pnz, src); B.sw = bcast(psw, src);
-          pre_bits = (pre_mask >> src) & (ncl >= 64 ? ~0ull : (1ull << ncl) - 1ull);
+          const int slot = pj & (pre_lpp - 1);
+          const float4 *q = reinterpret_cast<const float4 *>(my_pre + slot * 16); // (one address for the wave: broadcast reads)
+          const float4 q0 = q[0], q1 = q[1];
+          B.Dx = bcast(q0.x, 0); B.Dy = bcast(q0.y, 0); B.Dz = bcast(q0.z, 0); B.DD = bcast(q0.w, 0);
+          B.snx = bcast(q1.x, 0); B.sny = bcast(q1.y, 0); B.snz = bcast(q1.z, 0); B.sw = bcast(q1.w, 0);
+          pre_bits = (pre_mask >> (slot << pre_shift)) & (ncl >= 64 ? ~0ull : (1ull << ncl) - 1ull);
+#if defined(MRT_ABL_LIGHTS) && MRT_ABL_LIGHTS == 1 // timing only (wrong image): no shadow leaves at all
+          pre_bits = 0;
+#endif
         } else {
         B.DD = dot3(B.Dx, B.Dy, B.Dz, B.Dx, B.Dy, B.Dz);
         {
@@ -828,6 +860,9 @@ void render_cull_kernel(RenderArgs A)
             }
             unsigned long long mask = __ballot(pass);
             n_clusters++; n_exact += __popcll(mask);
+#if defined(MRT_ABL_LIGHTS) && MRT_ABL_LIGHTS == 2 // timing only: leaf bounds, no exact tests
+            if (LSPLIT) mask = 0;
+#endif
             while (mask) {
               const int j = __builtin_ctzll(mask);
               mask &= mask - 1;
@@ -873,6 +908,9 @@ void render_cull_kernel(RenderArgs A)
             if (i < nt) pass = bundle_may_touch(B, sc.tri_bx[i], sc.tri_by[i], sc.tri_bz[i], sc.tri_br[i]);
             unsigned long long mask = __ballot(pass);
             n_clusters++; n_exact += __popcll(mask);
+#if defined(MRT_ABL_LIGHTS) && MRT_ABL_LIGHTS == 2
+            if (LSPLIT) mask = 0;
+#endif
             while (mask) {
               const int j = __builtin_ctzll(mask);
               mask &= mask - 1;
@@ -929,7 +967,10 @@ void render_cull_kernel(RenderArgs A)
           if (member != 0) return; // member 0 shades
         }
         float lcr, lcg, lcb;
-        if constexpr (LSPLIT) { const int src = (pj << pre_shift) & 63; lcr = bcast(plr, src); lcg = bcast(plg, src); lcb = bcast(plb, src); }
+        if constexpr (LSPLIT) {
+          const float4 q3 = reinterpret_cast<const float4 *>(my_pre + (pj & (pre_lpp - 1)) * 16)[3];
+          lcr = bcast(q3.x, 0); lcg = bcast(q3.y, 0); lcb = bcast(q3.z, 0);
+        }
         else { lcr = sc.light_rgb[3 * li]; lcg = sc.light_rgb[3 * li + 1]; lcb = sc.light_rgb[3 * li + 2]; }
 #pragma unroll
         for (int p = 0; p < P; ++p) {
@@ -964,15 +1005,15 @@ void render_cull_kernel(RenderArgs A)
         }
       };
       for (int li = 0; li < sc.nl; ++li) {
-        if (!LSPLIT || (li % NWS) == member) {
-          const int pj = LSPLIT ? li / NWS : -1; // the light's place among this member's lights
+        if (!LSPLIT || light_owner(li) == member) {
+          const int pj = LSPLIT ? light_place(li) : -1; // the light's place among this member's lights
           float lvx, lvy, lvz;
           int lk;
           if constexpr (LSPLIT) {
-            if (((pj << pre_shift) & 63) == 0) precompute_pass(li); // the pass that starts with this light
-            const int src = (pj << pre_shift) & 63;                 // ... whose lanes also hold the lights themselves
-            lvx = bcast(plx, src); lvy = bcast(ply, src); lvz = bcast(plz, src);
-            lk = __builtin_amdgcn_readlane(plk, src);
+            if ((pj & (pre_lpp - 1)) == 0) precompute_pass(pj); // the pass that starts with this light
+            const float4 q2 = reinterpret_cast<const float4 *>(my_pre + (pj & (pre_lpp - 1)) * 16)[2]; // the light itself
+            lvx = bcast(q2.x, 0); lvy = bcast(q2.y, 0); lvz = bcast(q2.z, 0);
+            lk = __builtin_amdgcn_readfirstlane(__float_as_int(q2.w));
           } else {
             lvx = sc.light_vec[3 * li]; lvy = sc.light_vec[3 * li + 1]; lvz = sc.light_vec[3 * li + 2];
             lk = sc.light_kind[li];
@@ -983,14 +1024,29 @@ void render_cull_kernel(RenderArgs A)
         if constexpr (LSPLIT) {
           if ((li & (LCH - 1)) == LCH - 1 || li == sc.nl - 1) {
             __syncthreads(); // the chunk's contributions are in LDS
-            if (member == 0)
-              for (int k = li & ~(LCH - 1); k <= li; ++k) // result += light_bounce(...), in light order: core/light.cuh:171-173
-                if ((tm_lit[k & (LCH - 1)] >> lane) & 1ull) {
-                  const float cr = tm_c[(0 * LCH + (k & (LCH - 1))) * 64 + lane], cg = tm_c[(1 * LCH + (k & (LCH - 1))) * 64 + lane],
-                              cb = tm_c[(2 * LCH + (k & (LCH - 1))) * 64 + lane];
-                  if (have_light[0]) { lr[0] += cr; lg[0] += cg; lb[0] += cb; }
-                  else { lr[0] = cr; lg[0] = cg; lb[0] = cb; have_light[0] = true; }
+            if (member == 0) {
+              // result += light_bounce(...), in light order: core/light.cuh:171-173.  Four lights at a time, their slots
+              // read without a branch (a light that left nothing for a lane has its bit clear: the slot's old content is
+              // read and dropped) so that the twelve LDS reads are in flight together instead of one light after another
+              static_assert(LCH % 4 == 0, "the fold takes four lights at a time");
+              for (int k0 = li & ~(LCH - 1); k0 <= li; k0 += 4) {
+                float c[4][3];
+                bool lit[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                  const int kk = (k0 + u) & (LCH - 1);
+                  lit[u] = k0 + u <= li && ((tm_lit[kk] >> lane) & 1ull);
+                  c[u][0] = tm_c[(0 * LCH + kk) * 64 + lane]; c[u][1] = tm_c[(1 * LCH + kk) * 64 + lane]; c[u][2] = tm_c[(2 * LCH + kk) * 64 + lane];
                 }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                  const float nr = have_light[0] ? lr[0] + c[u][0] : c[u][0], ng = have_light[0] ? lg[0] + c[u][1] : c[u][1],
+                              nb = have_light[0] ? lb[0] + c[u][2] : c[u][2];
+                  lr[0] = lit[u] ? nr : lr[0]; lg[0] = lit[u] ? ng : lg[0]; lb[0] = lit[u] ? nb : lb[0];
+                  have_light[0] = have_light[0] || lit[u];
+                }
+              }
+            }
             __syncthreads(); // the slots are free for the next chunk
           }
         }
