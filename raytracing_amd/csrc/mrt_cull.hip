@@ -275,8 +275,10 @@ void render_cull_kernel(RenderArgs A)
     const int txn = (A.W + TW - 1) / TW, tyn = (A.local_rows + 7) >> 3;
     const int bxn = (txn + bs - 1) >> A.tile_map, nb = bxn * ((tyn + bs - 1) >> A.tile_map);
     const int w = blockIdx.x, x = w & 7, k = w >> 3;
-    const int b = x + 8 * (k / (bs * upr)), t = k % (bs * upr);
+    int b = x + 8 * (k / (bs * upr));
+    const int t = k % (bs * upr);
     if (b >= nb) return;
+    if (A.block_order) b = int(A.block_order[b]); // heaviest blocks first (block_order_kernel)
     tile_y = (b / bxn) * bs + t / upr;
     tile_x = (b % bxn) * bs + (t % upr) * wg_tiles + (NW > 1 ? 0 : wave);
     if (tile_y >= tyn) return;
@@ -284,8 +286,9 @@ void render_cull_kernel(RenderArgs A)
   if (tile_x * TW >= A.W) return; // NW == 1: waves are independent; NW > 1: the whole team leaves
   int leaf_k = 0; // leaf clusters met so far in the current walk (the same sequence in every member)
   [[maybe_unused]] int open_set = 0; // which set of tm_open the next merged light uses (the same in every member)
-#define MRT_TEAM_TAKES_LEAF() (NW == 1 || (leaf_k++ % NWS) == member)
-#define MRT_TEAM_TAKES_SHADOW_LEAF() (NW == 1 || LSPLIT || (leaf_k++ % NWS) == member)
+  [[maybe_unused]] bool solo = false; // a team's tile that member 0 renders alone (below: SOLO TILES)
+#define MRT_TEAM_TAKES_LEAF() (NW == 1 || solo || (leaf_k++ % NWS) == member)
+#define MRT_TEAM_TAKES_SHADOW_LEAF() (NW == 1 || LSPLIT || solo || (leaf_k++ % NWS) == member)
 #ifdef MRT_TIMELINE
   const unsigned tl_idx = tile_y * ((A.W + TW - 1) / TW) + tile_x;
   const unsigned long long tl_rt0 = __builtin_amdgcn_s_memrealtime(), tl_c0 = __builtin_amdgcn_s_memtime();
@@ -301,6 +304,37 @@ void render_cull_kernel(RenderArgs A)
   bool valid[P];
 #pragma unroll
   for (int p = 0; p < P; ++p) valid[p] = valid_row && (col0 + p < A.W);
+
+  // ---- the tile's lists (bin_primitives_kernel; "PRIMARY RAYS FROM BINS" below), looked up before anything else so that
+  //      the members of a team that have nothing to do on this tile leave early ----
+  const int gtile = (grow0 >> 3) * ((A.W + TW - 1) / TW) + tile_x; // the tile's number in the whole frame
+  bool binned_s = false, binned_t = false;
+  if constexpr (HIER && P == 1) {
+    if (A.bin_cnt && A.bin_cnt[0] == 0u) { // (word 0: the frame's near list overflowed -- nobody uses the bins)
+      const uint32_t cs = A.bin_cnt[BIN_HEAD + 2 * gtile], ct = A.bin_cnt[BIN_HEAD + 2 * gtile + 1];
+      binned_s = cs <= (uint32_t)A.bin_cap;
+      binned_t = ct <= (uint32_t)A.bin_cap;
+    }
+  }
+  // SOLO TILES.  A team is there for the tiles that are long jobs; most tiles are not (1M triangles at 4K: the median
+  // tile has three leaves and three exact tests, the 99th percentile 30 and 236), and on those four waves each pay
+  // for the tile's set-up, its rays, the merges and their barriers.  With lists the amount of work is known before
+  // it starts: a tile whose lists hold at most solo_max batches is rendered by member 0 alone -- as the one-wave
+  // kernel would, no merges, no barriers -- and the other members leave at once.  The counts are the same in every
+  // member, so is the decision.
+  if constexpr (NW > 1 && !LSPLIT && HIER && P == 1) {
+    if (binned_s && binned_t && A.bin_clusters && A.solo_max > 0) {
+      uint32_t jobs = A.bin_cnt[BIN_HEAD + 2 * gtile] + A.bin_cnt[BIN_HEAD + 2 * gtile + 1] + A.bin_cnt[1] + A.bin_cnt[2];
+      if (A.loose_cnt != nullptr) {
+        const uint32_t lc = A.loose_cnt[(grow0 >> LOOSE_BLOCK_SHIFT) * A.loose_bx + ((tile_x * TW) >> LOOSE_BLOCK_SHIFT)];
+        jobs += lc > (uint32_t)A.loose_cap ? 1u << 20 : (lc + 63u) >> 6;
+      } else {
+        jobs += (uint32_t)(sc.nct - A.bin_nct_regular); // the loose clusters are walked
+      }
+      solo = jobs <= (uint32_t)A.solo_max;
+      if (solo && member != 0) return;
+    }
+  }
 
   // ---- cone around the tile's rays, padded by one pixel on every side (which also covers the sub-pixel
   //      offsets of the 121-spp pattern, within (-11/13, +9/13) pixel).  d(u,v) is affine in (u,v), so every
@@ -439,19 +473,27 @@ void render_cull_kernel(RenderArgs A)
     // frame: lane = primitive, which tiles' cones may touch its ball? -- and leaves a list per tile (the same cone, the
     // same test: the list holds exactly the primitives the walk's leaves would have passed).  A tile whose lists fit
     // takes its candidates from them; one whose lists overflowed (a horizon: thousands of sub-pixel triangles) walks.
-    const int gtile = (grow0 >> 3) * ((A.W + TW - 1) / TW) + tile_x; // the tile's number in the whole frame
-    bool binned_s = false, binned_t = false;
-    if constexpr (HIER && P == 1) {
-      if (A.bin_cnt && A.bin_cnt[0] == 0u) { // (word 0: the frame's near list overflowed -- nobody uses the bins)
-        const uint32_t cs = A.bin_cnt[BIN_HEAD + 2 * gtile], ct = A.bin_cnt[BIN_HEAD + 2 * gtile + 1];
-        binned_s = cs <= (uint32_t)A.bin_cap;
-        binned_t = ct <= (uint32_t)A.bin_cap;
-      }
-    }
     leaf_k = 0;
     if (binned_s) {
       const uint32_t cs = A.bin_cnt[BIN_HEAD + 2 * gtile], cn = A.bin_cnt[1];
       const uint32_t *list = A.bin_list + size_t(2 * gtile) * A.bin_cap;
+      if (A.bin_clusters) {
+        // the lists hold leaf clusters (scenes of more primitives than tiles): the walk's leaves without the walk --
+        // which a team would otherwise repeat in each of its members
+        auto leaves = [&](const uint32_t *l, uint32_t n) {
+          for (uint32_t k0 = 0; k0 < n; k0 += 64) {
+            const int mine = k0 + lane < n ? int(l[k0 + lane]) : 0;
+            const int m = int(min(n - k0, 64u));
+            for (int k = 0; k < m; ++k) {
+              if (!MRT_TEAM_TAKES_LEAF()) continue;
+              const int base = __builtin_amdgcn_readlane(mine, k) * 64;
+              sphere_batch(base + lane, base + lane < ns, base, false);
+            }
+          }
+        };
+        leaves(list, cs);
+        leaves(A.bin_near, cn);
+      } else {
       for (uint32_t k0 = 0; k0 < cs; k0 += 64) {
         if (!MRT_TEAM_TAKES_LEAF()) continue;
         const bool have = k0 + lane < cs;
@@ -461,6 +503,7 @@ void render_cull_kernel(RenderArgs A)
         if (!MRT_TEAM_TAKES_LEAF()) continue;
         const bool have = k0 + lane < cn;
         sphere_batch(have ? int(A.bin_near[k0 + lane]) : 0, have, -1, false);
+      }
       }
     } else {
     walk_hierarchy<HIER>(sc.sph_sclu, sc.nscs, sc.sph_clu, sc.ncs, lane, sphere_ball_in_reach, [&](int base) {
@@ -524,6 +567,21 @@ void render_cull_kernel(RenderArgs A)
       // the regular triangles from the tile's list (the loose ones follow from their block's list, or all of them)
       const uint32_t ct = A.bin_cnt[BIN_HEAD + 2 * gtile + 1], cn = A.bin_cnt[2];
       const uint32_t *list = A.bin_list + size_t(2 * gtile + 1) * A.bin_cap;
+      if (A.bin_clusters) {
+        auto leaves = [&](const uint32_t *l, uint32_t n) {
+          for (uint32_t k0 = 0; k0 < n; k0 += 64) {
+            const int mine = k0 + lane < n ? int(l[k0 + lane]) : 0;
+            const int m = int(min(n - k0, 64u));
+            for (int k = 0; k < m; ++k) {
+              if (!MRT_TEAM_TAKES_LEAF()) continue;
+              const int base = __builtin_amdgcn_readlane(mine, k) * 64, i = base + lane;
+              triangle_batch(i, i < nt && tri_ball_in_reach(sc.tri_bx[i], sc.tri_by[i], sc.tri_bz[i], sc.tri_br[i]), base);
+            }
+          }
+        };
+        leaves(list, ct);
+        leaves(A.bin_near + BIN_NEAR_CAP, cn);
+      } else {
       for (uint32_t k0 = 0; k0 < ct; k0 += 64) {
         if (!MRT_TEAM_TAKES_LEAF()) continue;
         const bool have = k0 + lane < ct;
@@ -534,6 +592,7 @@ void render_cull_kernel(RenderArgs A)
         const bool have = k0 + lane < cn;
         const int i = have ? int(A.bin_near[BIN_NEAR_CAP + k0 + lane]) : 0;
         triangle_batch(i, have && tri_ball_in_reach(sc.tri_bx[i], sc.tri_by[i], sc.tri_bz[i], sc.tri_br[i]), -1);
+      }
       }
       if (!use_lists) // no block lists for the loose triangles: their clusters are walked
         for (int base = A.bin_nct_regular * 64; base < nt; base += 64) {
@@ -573,7 +632,7 @@ void render_cull_kernel(RenderArgs A)
       }
     }
 
-    if constexpr (NW > 1) {
+    if (NW > 1 && !solo) {
       // the team's closest hit: the minimum of the members' (t, object) under the same rule as inside a member
       tm_t[member * 64 + lane] = best_t[0]; tm_obj[member * 64 + lane] = best_obj[0]; tm_prim[member * 64 + lane] = best_prim[0];
       __syncthreads();
@@ -949,7 +1008,7 @@ void render_cull_kernel(RenderArgs A)
         }
 
         if constexpr (NW > 1 && !LSPLIT) {
-          if (team_need) {
+          if (team_need && !solo) {
             // a shadow ray is free only if no member found an occluder: AND of the members' masks.  The two sets of
             // slots alternate between the lights that GET HERE (team_need is the same in every member), so one barrier
             // per such light is enough: whoever writes a set again has passed the barrier of the light in between,
@@ -1226,10 +1285,25 @@ struct BinCamera {
   float lh, lv;                             // lengths of the horizontal and vertical edges
 };
 enum { BIN_MAX_RECT = 4096, BIN_DIRECT = 4, BIN_QUEUE_CAP = 1 << 18 };
-// the ball of primitive g (spheres first, then triangles) as the tile kernel tests it against a cone: centre - origin, radius
-__device__ __forceinline__ void bin_ball(const DevScene &sc, const DevCamera &cam, int g, float &wx, float &wy, float &wz, float &reff)
+// the ball of item g (spheres first, then triangles; A.bin_clusters: leaf clusters of spheres, then of triangles) as the
+// tile kernel tests it against a cone: centre - origin, radius
+__device__ __forceinline__ int bin_items0(const RenderArgs &A) { return A.bin_clusters ? A.sc.ncs : A.sc.ns; }
+__device__ __forceinline__ int bin_items1(const RenderArgs &A) { return A.bin_clusters ? A.bin_nct_regular : min(A.sc.nt, A.bin_nct_regular * 64); }
+__device__ __forceinline__ void bin_ball(const RenderArgs &A, int g, float &wx, float &wy, float &wz, float &reff)
 {
-  if (g < sc.ns) {
+  const DevScene &sc = A.sc;
+  const DevCamera &cam = A.cam;
+  if (A.bin_clusters) {
+    if (g < sc.ncs) {
+      const float R = sc.sph_clu[3 * sc.ncs + g];
+      wx = sc.sph_clu[g] - cam.ox; wy = sc.sph_clu[sc.ncs + g] - cam.oy; wz = sc.sph_clu[2 * sc.ncs + g] - cam.oz;
+      reff = cluster_cull_radius(R, fast_sqrt(dot3(wx, wy, wz, wx, wy, wz)) * CULL_REL + R); // as cone_vs_sphere_ball
+    } else {
+      const int k = g - sc.ncs;
+      wx = sc.tri_clu[k] - cam.ox; wy = sc.tri_clu[sc.nct + k] - cam.oy; wz = sc.tri_clu[2 * sc.nct + k] - cam.oz;
+      reff = sc.tri_clu[3 * sc.nct + k] * CULL_REL + CULL_ABS;                              // as cone_vs_tri_ball
+    }
+  } else if (g < sc.ns) {
     const float r = sc.sph_r[g];
     wx = sc.sph_cx[g] - cam.ox; wy = sc.sph_cy[g] - cam.oy; wz = sc.sph_cz[g] - cam.oz;
     reff = sphere_cull_radius(r * r, dot3(wx, wy, wz, wx, wy, wz)); // as sphere_batch
@@ -1245,10 +1319,11 @@ __device__ __forceinline__ void bin_try_tile(const RenderArgs &A, int TW, int ti
 {
   const TileCone t = make_tile_cone(A.cam, A.W, A.H, A.cone_ext, tx, TW, ty * 8);
   if (!ball_may_touch_cone(wx, wy, wz, reff, t.cax, t.cay, t.caz, t.cosT, t.sinT)) return;
-  const bool tri = g >= A.sc.ns;
+  const int n0 = bin_items0(A);
+  const bool tri = g >= n0;
   const int slot = 2 * (ty * tiles_x + tx) + (tri ? 1 : 0);
   const uint32_t pos = atomicAdd(&cnt[BIN_HEAD + slot], 1u);
-  if (pos < (uint32_t)A.bin_cap) list[size_t(slot) * A.bin_cap + pos] = (uint32_t)(tri ? g - A.sc.ns : g);
+  if (pos < (uint32_t)A.bin_cap) list[size_t(slot) * A.bin_cap + pos] = (uint32_t)(tri ? g - n0 : g);
 }
 
 // Pass 1, lane = primitive: the rectangle; small ones (up to BIN_DIRECT tiles: the million sub-pixel triangles of a
@@ -1258,13 +1333,12 @@ __global__ __launch_bounds__(256) void bin_primitives_kernel(RenderArgs A, BinCa
                                                              uint32_t *__restrict__ list, uint32_t *__restrict__ near_list,
                                                              uint2 *__restrict__ queue)
 {
-  const DevScene &sc = A.sc;
   const int g = blockIdx.x * 256 + threadIdx.x;
-  const int ns = sc.ns, ntr = min(sc.nt, A.bin_nct_regular * 64);
+  const int ns = bin_items0(A), ntr = bin_items1(A); // (items of the first and of the second kind)
   const bool live = g < ns + ntr; // (lanes past the last primitive stay: the wave shares the larger rectangles out)
   const bool tri = g >= ns;
   float wx = 0.0f, wy = 0.0f, wz = 0.0f, reff = 0.0f;
-  if (live) bin_ball(sc, A.cam, g, wx, wy, wz, reff);
+  if (live) bin_ball(A, g, wx, wy, wz, reff);
   const int tiles_x = (A.W + TW - 1) / TW, tiles_y = (A.H + 7) >> 3;
   int tx0 = 0, tx1 = -1, ty0 = 0, ty1 = -1;
   bool near = live;
@@ -1331,9 +1405,53 @@ __global__ __launch_bounds__(256) void bin_blocks_kernel(RenderArgs A, int TW, u
     const uint2 e = queue[q];
     const int g = int(e.x), tx = int(e.y & 0xffffu) * 8 + (lane & 7), ty = int(e.y >> 16) * 8 + (lane >> 3);
     float wx, wy, wz, reff;
-    bin_ball(A.sc, A.cam, g, wx, wy, wz, reff);
+    bin_ball(A, g, wx, wy, wz, reff);
     if (tx < tiles_x && ty < tiles_y) bin_try_tile(A, TW, tiles_x, g, wx, wy, wz, reff, tx, ty, cnt, list);
   }
+}
+
+// ---- start order of the blocks of tiles: heaviest first ---------------------------------------------------------
+// With lists the work of a tile is known before the frame starts.  On a terrain the few tiles along the horizon are
+// jobs of a millisecond (1 800 exact tests against a median of 35); in frame order they start two thirds into the frame
+// and the GPU drains for 0.2 ms behind the last of them.  block_weight_kernel (wave = block of 2^map x 2^map tiles as
+// the tile kernel numbers them, lane = tile) takes the largest list of each block, block_order_kernel (one workgroup)
+// sorts the blocks by it, descending, with a counting sort; the tile kernel looks its block up in the result.
+// Results do not depend on the order.
+__global__ __launch_bounds__(256) void block_weight_kernel(RenderArgs A, int TW, int map, uint32_t *__restrict__ weight)
+{
+  const int lane = threadIdx.x & 63, bs = 1 << map;
+  const int txn = (A.W + TW - 1) / TW, tyn = (A.local_rows + 7) >> 3;
+  const int bxn = (txn + bs - 1) >> map, nb = bxn * ((tyn + bs - 1) >> map);
+  const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (b >= nb) return;
+  uint32_t w = 0;
+  for (int t = lane; t < bs * bs; t += 64) {
+    const int tile_x = (b % bxn) * bs + (t & (bs - 1)), tile_y = (b / bxn) * bs + (t >> map);
+    if (tile_x < txn && tile_y < tyn) {
+      const int lrow0 = tile_y * 8, strip = lrow0 / A.strip_rows;
+      const int grow0 = (strip * A.nranks + A.rank) * A.strip_rows + (lrow0 - strip * A.strip_rows);
+      if (grow0 < A.H) {
+        const int gtile = (grow0 >> 3) * txn + tile_x;
+        w = max(w, A.bin_cnt[BIN_HEAD + 2 * gtile] + A.bin_cnt[BIN_HEAD + 2 * gtile + 1]);
+      }
+    }
+  }
+  w = (uint32_t)wave_max((float)min(w, 1023u));
+  if (lane == 0) weight[b] = w;
+}
+__global__ __launch_bounds__(1024) void block_order_kernel(int nb, const uint32_t *__restrict__ weight, uint32_t *__restrict__ order)
+{
+  __shared__ uint32_t hist[1024], start[1024];
+  for (int i = threadIdx.x; i < 1024; i += 1024) hist[i] = 0;
+  __syncthreads();
+  for (int b = threadIdx.x; b < nb; b += 1024) atomicAdd(&hist[1023u - min(weight[b], 1023u)], 1u); // key 0 = heaviest
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint32_t acc = 0;
+    for (int i = 0; i < 1024; ++i) { start[i] = acc; acc += hist[i]; }
+  }
+  __syncthreads();
+  for (int b = threadIdx.x; b < nb; b += 1024) order[atomicAdd(&start[1023u - min(weight[b], 1023u)], 1u)] = (uint32_t)b;
 }
 
 // entries per tile and primitive type: two batches
@@ -1342,40 +1460,44 @@ __global__ __launch_bounds__(256) void bin_blocks_kernel(RenderArgs A, int TW, u
 #endif
 // Bins apply to scenes with a hierarchy to walk, one pixel per lane, and a camera whose image is a rectangle (horizontal
 // and vertical edges perpendicular: what rt::Viewport makes; anything else walks).  MRT_BINS=0 switches them off.
-static bool bins_apply(const RenderArgs &A, BinCamera *out)
+// -> 0: no bins; 1: lists of primitives; 2: lists of leaf clusters.
+static int bins_apply(const RenderArgs &A, BinCamera *out)
 {
-  static const bool on = !(getenv("MRT_BINS") && atoi(getenv("MRT_BINS")) == 0);
-  // (below a few thousand primitives the walk is a handful of steps per tile and not worth two more launches; with
-  // more primitives than tiles the lists cost more than the walks they save: 1M triangles at 4K 2.45 -> 2.69 ms
-  // with them -- a tile there spends its time on the exact tests, which the lists do not change -- 10k spheres
-  // 0.437 -> 0.368 ms.  MRT_BINS=2 lifts the upper limit for measurements.)
-  static const bool any = getenv("MRT_BINS") && atoi(getenv("MRT_BINS")) == 2;
+  // MRT_BINS = 0: off; 1: lists of primitives whatever the scene; 2: lists of clusters whatever the scene (measurements)
+  static const int env = getenv("MRT_BINS") ? atoi(getenv("MRT_BINS")) : -1;
+  // Below a few thousand primitives the walk is a handful of steps per tile and not worth two more launches.  With
+  // fewer primitives than tiles the lists hold primitives (10k spheres at 4K 0.437 -> 0.355 ms).  With more -- 1M
+  // triangles at 4K: 12 M appends, and a tile spends its time on exact tests that lists do not change: 2.45 -> 2.69 ms
+  // with lists of primitives -- they hold leaf clusters, a hundredth as many items: what is saved is the upper levels
+  // of the walk, which a team repeats in every member.
   const long nprim = (long)A.sc.ns + A.sc.nt, ntile = (long)((A.W + 7) / 8) * ((A.H + 7) / 8);
-  if (!on || nprim < 2048 || (nprim > ntile && !any)) return false;
+  if (env == 0 || nprim < 2048) return 0;
+  const int mode = env == 1 ? 1 : env == 2 ? 2 : (nprim > ntile ? 2 : 1);
   const double h[3] = {A.cam.hx, A.cam.hy, A.cam.hz}, v[3] = {A.cam.vx, A.cam.vy, A.cam.vz};
   const double b[3] = {(double)A.cam.ux - A.cam.ox, (double)A.cam.uy - A.cam.oy, (double)A.cam.uz - A.cam.oz};
   auto dot = [](const double *x, const double *y) { return x[0] * y[0] + x[1] * y[1] + x[2] * y[2]; };
   const double lh = std::sqrt(dot(h, h)), lv = std::sqrt(dot(v, v));
-  if (!(lh > 1e-30) || !(lv > 1e-30) || !std::isfinite(lh) || !std::isfinite(lv)) return false;
+  if (!(lh > 1e-30) || !(lv > 1e-30) || !std::isfinite(lh) || !std::isfinite(lv)) return 0;
   const double hu[3] = {h[0] / lh, h[1] / lh, h[2] / lh}, vu[3] = {v[0] / lv, v[1] / lv, v[2] / lv};
-  if (!(std::fabs(dot(hu, vu)) < 1e-4)) return false;
+  if (!(std::fabs(dot(hu, vu)) < 1e-4)) return 0;
   double n[3] = {hu[1] * vu[2] - hu[2] * vu[1], hu[2] * vu[0] - hu[0] * vu[2], hu[0] * vu[1] - hu[1] * vu[0]};
   double bn = dot(b, n);
   if (bn < 0) { bn = -bn; n[0] = -n[0]; n[1] = -n[1]; n[2] = -n[2]; }
-  if (!(bn > 1e-6 * (std::fabs(dot(b, hu)) + std::fabs(dot(b, vu)) + lh + lv)) || !std::isfinite(bn)) return false;
+  if (!(bn > 1e-6 * (std::fabs(dot(b, hu)) + std::fabs(dot(b, vu)) + lh + lv)) || !std::isfinite(bn)) return 0;
   if (out) {
     out->hx = (float)hu[0]; out->hy = (float)hu[1]; out->hz = (float)hu[2];
     out->vx = (float)vu[0]; out->vy = (float)vu[1]; out->vz = (float)vu[2];
     out->nx = (float)n[0]; out->ny = (float)n[1]; out->nz = (float)n[2];
     out->bh = (float)dot(b, hu); out->bv = (float)dot(b, vu); out->bn = (float)bn; out->lh = (float)lh; out->lv = (float)lv;
   }
-  return true;
+  return mode;
 }
 static size_t bins_bytes(const RenderArgs &A)
 {
   if (!bins_apply(A, nullptr)) return 0;
   const size_t tiles = size_t((A.W + 7) / 8) * size_t((A.H + 7) / 8);
-  return ((BIN_HEAD + 2 * tiles) * 4 + 255) / 256 * 256 + 2 * BIN_NEAR_CAP * 4 + (size_t)BIN_QUEUE_CAP * 8 + 2 * tiles * MRT_BIN_CAP * 4;
+  // (+ the blocks' weights and start order: at most one block per tile)
+  return ((BIN_HEAD + 2 * tiles) * 4 + 255) / 256 * 256 + 2 * BIN_NEAR_CAP * 4 + (size_t)BIN_QUEUE_CAP * 8 + 2 * tiles * MRT_BIN_CAP * 4 + 2 * tiles * 4;
 }
 
 // Waves per tile for a scene (render_cull_kernel's NW and LSPLIT).  A team pays for itself when single tiles are long
@@ -1421,11 +1543,14 @@ static hipError_t launch_cull(RenderArgs &A, hipStream_t stream)
   if (tiles_x == 0 || tiles_y == 0) return hipSuccess;
   if constexpr (HIER && P == 1) {
     BinCamera C;
-    if (A.bin_cnt && bins_apply(A, &C)) {
+    const int bmode = A.bin_cnt ? bins_apply(A, &C) : 0;
+    if (bmode) {
+      A.bin_clusters = bmode == 2;
       const size_t tiles = size_t((A.W + 7) / 8) * size_t((A.H + 7) / 8);
       hipError_t e = hipMemsetAsync((void *)A.bin_cnt, 0, (BIN_HEAD + 2 * tiles) * 4, stream);
       if (e != hipSuccess) return e;
-      const long nprim = (long)A.sc.ns + std::min<long>(A.sc.nt, (long)A.bin_nct_regular * 64);
+      const long nprim = A.bin_clusters ? (long)A.sc.ncs + A.bin_nct_regular
+                                        : (long)A.sc.ns + std::min<long>(A.sc.nt, (long)A.bin_nct_regular * 64);
       uint2 *queue = (uint2 *)(A.bin_near + 2 * BIN_NEAR_CAP);
       if (nprim > 0) {
         hipLaunchKernelGGL(bin_primitives_kernel, dim3((unsigned)((nprim + 255) / 256)), dim3(256), 0, stream, A, C, 8,
@@ -1446,6 +1571,21 @@ static hipError_t launch_cull(RenderArgs &A, hipStream_t stream)
   // coarser interleaving of cheap and expensive tiles (10k spheres 421 -> 432 us, 64 lights 1141 -> 1155 us).
   static const int xcd = getenv("MRT_CULL_XCD") ? atoi(getenv("MRT_CULL_XCD")) : -1;
   A.tile_map = !HIER ? 0 : xcd >= 0 ? (xcd > 6 ? 6 : xcd) : ((long)A.sc.ns + A.sc.nt >= 100000 ? 3 : 0);
+  A.block_order = nullptr;
+  if constexpr (HIER && P == 1) {
+    static const bool order_on = !(getenv("MRT_CULL_ORDER") && atoi(getenv("MRT_CULL_ORDER")) == 0);
+    if (A.bin_cnt && A.tile_map && order_on) { // the blocks start heaviest first (block_weight_kernel)
+      const size_t tiles = size_t((A.W + 7) / 8) * size_t((A.H + 7) / 8);
+      const int bs = 1 << A.tile_map;
+      const int nb = ((tiles_x + bs - 1) / bs) * ((tiles_y + bs - 1) / bs);
+      uint32_t *weight = (uint32_t *)A.bin_list + 2 * tiles * (size_t)A.bin_cap, *order = weight + tiles;
+      hipLaunchKernelGGL(block_weight_kernel, dim3((unsigned)((nb + 3) / 4)), dim3(256), 0, stream, A, 8, A.tile_map, weight);
+      hipLaunchKernelGGL(block_order_kernel, dim3(1), dim3(1024), 0, stream, nb, (const uint32_t *)weight, order);
+      hipError_t e = hipGetLastError();
+      if (e != hipSuccess) return e;
+      A.block_order = order;
+    }
+  }
   // waves per workgroup: waves share nothing; 2 measured best on C3 and C5 (413 / 1561 us against 444 / 1625 with 4)
   static const int wpw = getenv("MRT_CULL_WPW") ? atoi(getenv("MRT_CULL_WPW")) : 2;
   if constexpr (HIER && P == 1) {
@@ -1494,6 +1634,8 @@ hipError_t launch_render_cull(const RenderArgs &in, void *loose_scratch, hipStre
     A.bin_near = (const uint32_t *)(b + ((BIN_HEAD + 2 * tiles) * 4 + 255) / 256 * 256);
     A.bin_list = A.bin_near + 2 * BIN_NEAR_CAP + 2 * (size_t)BIN_QUEUE_CAP; // (the queue of the two binning passes sits in between)
     A.bin_cap = MRT_BIN_CAP;
+    static const int solo_max = getenv("MRT_CULL_SOLO") ? atoi(getenv("MRT_CULL_SOLO")) : 48;
+    A.solo_max = solo_max;
     A.bin_nct_regular = A.sc.nct_regular;
   }
   if (loose_scratch && loose_lists_apply(A)) {

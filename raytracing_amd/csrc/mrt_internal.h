@@ -90,6 +90,7 @@ struct RenderArgs {
   int32_t wide;
   float cone_ext;                   // cull kernel: max |ray - tile centre ray| over a padded tile (launcher)
   int32_t tile_map;                 // cull kernel: 0 tiles in row order (2-D grid), n: XCD-aware blocks of 2^n x 2^n tiles (1-D grid)
+  const uint32_t *block_order;      // with tile_map: the blocks in the order they are to start (heaviest first), or null: as numbered
   int32_t team_mode;                // cull kernel, MRT_OPT_CULL_TEAM: 0 automatic, 1 one wave per tile, 4 teams dealing leaves, 5 dealing lights
   // diffuse bounces (mrt_bounce.hip, mrt_rng.hip): xorshift words of pixel i at rng[k * rng_stride + i], k = 0..4,
   // and the Weyl counter every stream starts with; null when no stream is needed
@@ -113,6 +114,8 @@ struct RenderArgs {
   const uint32_t *bin_near;
   int32_t bin_cap;
   int32_t bin_nct_regular;              // triangle clusters the bins cover (the loose ones behind them are not binned)
+  int32_t bin_clusters;                 // 0: the lists hold primitives; 1: leaf clusters of 64 (scenes of more primitives than tiles)
+  int32_t solo_max;                     // teams dealing leaves: a tile with at most this many batches listed is rendered by member 0 alone
 };
 
 hipError_t launch_render_cull(const RenderArgs &args, hipStream_t stream);
