@@ -150,8 +150,16 @@ const char *mrt_status_string(int status);
  * (camera + frame size) and, when the same view is rendered again, starts the launch at the tile row where the
  * geometry begins (a scheduling choice: identical buffers).  0 = every render is treated as the first of its view,
  * which is what a camera that moves every frame gets anyway (bench.py reports that time as first_view_ms).
+ * MRT_OPT_LISTS (no reference counterpart; default 0): where the tile-culling kernel's tiles get the candidates of their
+ * primary rays from -- 0 = by the scene (per-tile lists of primitives from 2 048 primitives on when there are fewer
+ * primitives than tiles, lists of 64-primitive leaf clusters when there are more, per-block lists of the loose
+ * triangles), 1 = no lists: every tile walks the hierarchy, 2 = lists of primitives and 3 = lists of leaf clusters
+ * whatever the scene's size.  Identical buffers in every mode.  MRT_OPT_LIST_CAP (test hook; default 0 = the built-in
+ * sizes) shortens every list to that many entries, so that small frames reach the overflow paths (a tile whose list
+ * overflowed walks the hierarchy, a block whose list overflowed takes every loose triangle).
  */
-enum { MRT_OPT_CULL = 1, MRT_OPT_RNG_SEED = 2, MRT_OPT_FAIL_NEXT_UPLOAD = 3, MRT_OPT_CULL_TEAM = 4, MRT_OPT_VIEW_CACHE = 5 };
+enum { MRT_OPT_CULL = 1, MRT_OPT_RNG_SEED = 2, MRT_OPT_FAIL_NEXT_UPLOAD = 3, MRT_OPT_CULL_TEAM = 4, MRT_OPT_VIEW_CACHE = 5,
+       MRT_OPT_LISTS = 6, MRT_OPT_LIST_CAP = 7 };
 int mrt_ctx_set_option(mrt_ctx *ctx, int option, int value);
 
 /*

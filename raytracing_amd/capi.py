@@ -401,6 +401,13 @@ class Context:
         of four dealing leaf clusters, 5 teams of four dealing lights.  Identical outputs."""
         self._check(self._L.mrt_ctx_set_option(self._h, 4, int(mode)), "mrt_ctx_set_option")
 
+    def set_lists(self, mode, cap=0):
+        """MRT_OPT_LISTS: where the tile-culling kernel's tiles get their primary candidates from -- 0 by the scene,
+        1 no lists (walk), 2 lists of primitives, 3 lists of leaf clusters; cap > 0 (MRT_OPT_LIST_CAP, test hook)
+        shortens every list so that small frames reach the overflow paths.  Identical outputs."""
+        self._check(self._L.mrt_ctx_set_option(self._h, 6, int(mode)), "mrt_ctx_set_option")
+        self._check(self._L.mrt_ctx_set_option(self._h, 7, int(cap)), "mrt_ctx_set_option")
+
     def set_view_cache(self, on):
         """MRT_OPT_VIEW_CACHE: False = the small-scene launcher treats every render as the first of its view."""
         self._check(self._L.mrt_ctx_set_option(self._h, 5, 1 if on else 0), "mrt_ctx_set_option")

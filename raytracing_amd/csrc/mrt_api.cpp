@@ -42,6 +42,7 @@ struct mrt_ctx {
   unsigned long long *stats_dev = nullptr;
   int cull = 1; // MRT_OPT_CULL value
   int team = 0; // MRT_OPT_CULL_TEAM value
+  int lists = 0, list_cap = 0; // MRT_OPT_LISTS, MRT_OPT_LIST_CAP
 
   // u = col / W, v = row / H tables of the small-scene kernel, one entry per frame size seen, kept until the
   // context goes (a frame size costs (W + H) floats)
@@ -329,6 +330,16 @@ int mrt_ctx_set_option(mrt_ctx *ctx, int option, int value)
   if (option == MRT_OPT_CULL_TEAM) {
     if (value != 0 && value != 1 && value != 4 && value != 5) return fail(ctx, MRT_ERR_INVALID, "MRT_OPT_CULL_TEAM takes 0, 1, 4 or 5");
     ctx->team = value;
+    return MRT_OK;
+  }
+  if (option == MRT_OPT_LISTS) {
+    if (value < 0 || value > 3) return fail(ctx, MRT_ERR_INVALID, "MRT_OPT_LISTS takes 0, 1, 2 or 3");
+    ctx->lists = value;
+    return MRT_OK;
+  }
+  if (option == MRT_OPT_LIST_CAP) {
+    if (value < 0 || value > 0x7fff) return fail(ctx, MRT_ERR_INVALID, "MRT_OPT_LIST_CAP takes 0 (the built-in sizes) or a number of entries up to 32767");
+    ctx->list_cap = value;
     return MRT_OK;
   }
   if (option == MRT_OPT_FAIL_NEXT_UPLOAD) {
@@ -663,7 +674,7 @@ static int fill_args(mrt_ctx *ctx, const mrt_camera *cam, const mrt_render_param
   A.spp = p->spp;
   A.max_depth = p->max_depth;
   A.stats_slots = 1;
-  A.team_mode = ctx->team;
+  A.team_mode = ctx->team | (ctx->lists << 8) | (ctx->list_cap << 16); // opt_team / opt_lists / opt_list_cap
   return MRT_OK;
 }
 

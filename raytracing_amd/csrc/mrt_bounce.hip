@@ -1039,7 +1039,7 @@ hipError_t launch_render_bounce(const RenderArgs &in, const SmallHost *hs, uint3
     // the two-wave pipeline per tile (mrt_bounce_pipe.hip); MRT_BOUNCE_PIPE=0: the one-wave kernel it replaced
     // (also MRT_OPT_CULL_TEAM = 1, "one wave per tile": the tests run both)
     static const bool pipe = !(getenv("MRT_BOUNCE_PIPE") && atoi(getenv("MRT_BOUNCE_PIPE")) == 0);
-    if (pipe && in.team_mode != 1) return launch_render_bounce_pipe(S, stream);
+    if (pipe && opt_team(in) != 1) return launch_render_bounce_pipe(S, stream);
     const dim3 sgrid((ntiles + MRT_BOUNCE_WPB - 1) / MRT_BOUNCE_WPB), sblock(64 * MRT_BOUNCE_WPB);
     if (in.spp > 1) hipLaunchKernelGGL(render_bounce_small_kernel<true>, sgrid, sblock, 0, stream, S);
     else hipLaunchKernelGGL(render_bounce_small_kernel<false>, sgrid, sblock, 0, stream, S);

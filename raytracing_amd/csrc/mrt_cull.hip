@@ -1260,7 +1260,8 @@ static bool loose_lists_apply(const RenderArgs &A)
   static const bool on = !(getenv("MRT_LOOSE_LISTS") && atoi(getenv("MRT_LOOSE_LISTS")) == 0);
   static const long least = getenv("MRT_LOOSE_MIN") ? atol(getenv("MRT_LOOSE_MIN")) : 256; // (stress runs: 1)
   const long nloose = (long)A.sc.nt - (long)A.sc.nct_regular * 64;
-  return on && A.sc.nct > 1 && A.sc.nct_regular < A.sc.nct && nloose >= least && nloose <= 65536 && A.spp == 1;
+  if (opt_lists(A) == 1) return false; // MRT_OPT_LISTS: every tile walks
+  return on && A.sc.nct > 1 && A.sc.nct_regular < A.sc.nct && nloose >= (opt_list_cap(A) > 0 ? 1 : least) && nloose <= 65536 && A.spp == 1;
 }
 static size_t loose_bytes(const RenderArgs &A)
 {
@@ -1471,8 +1472,9 @@ static int bins_apply(const RenderArgs &A, BinCamera *out)
   // with lists of primitives -- they hold leaf clusters, a hundredth as many items: what is saved is the upper levels
   // of the walk, which a team repeats in every member.
   const long nprim = (long)A.sc.ns + A.sc.nt, ntile = (long)((A.W + 7) / 8) * ((A.H + 7) / 8);
-  if (env == 0 || nprim < 2048) return 0;
-  const int mode = env == 1 ? 1 : env == 2 ? 2 : (nprim > ntile ? 2 : 1);
+  const int pinned = opt_lists(A) >= 2 ? opt_lists(A) - 1 : 0; // MRT_OPT_LISTS 2 | 3: whatever the scene (tests, stress runs)
+  if (opt_lists(A) == 1 || (!pinned && (env == 0 || nprim < 2048))) return 0;
+  const int mode = pinned ? pinned : env == 1 ? 1 : env == 2 ? 2 : (nprim > ntile ? 2 : 1);
   const double h[3] = {A.cam.hx, A.cam.hy, A.cam.hz}, v[3] = {A.cam.vx, A.cam.vy, A.cam.vz};
   const double b[3] = {(double)A.cam.ux - A.cam.ox, (double)A.cam.uy - A.cam.oy, (double)A.cam.uz - A.cam.oz};
   auto dot = [](const double *x, const double *y) { return x[0] * y[0] + x[1] * y[1] + x[2] * y[2]; };
@@ -1515,7 +1517,7 @@ static int team_mode(const RenderArgs &A)
     const int x = e ? atoi(e) : 0;
     return (x == 1 || x == 4 || x == 5) ? x : 0;
   }();
-  const int forced = A.team_mode ? A.team_mode : env;
+  const int forced = opt_team(A) ? opt_team(A) : env;
   if (forced == 5 && A.sc.ncs + A.sc.nct > 64) return 4; // see below
   if (forced) return forced;
   // (teams dealing lights set the lights' shadow walks up lane-parallel over (light, cluster) pairs: at most 64 clusters)
@@ -1633,7 +1635,7 @@ hipError_t launch_render_cull(const RenderArgs &in, void *loose_scratch, hipStre
     A.bin_cnt = (const uint32_t *)b;
     A.bin_near = (const uint32_t *)(b + ((BIN_HEAD + 2 * tiles) * 4 + 255) / 256 * 256);
     A.bin_list = A.bin_near + 2 * BIN_NEAR_CAP + 2 * (size_t)BIN_QUEUE_CAP; // (the queue of the two binning passes sits in between)
-    A.bin_cap = MRT_BIN_CAP;
+    A.bin_cap = opt_list_cap(A) > 0 && opt_list_cap(A) < MRT_BIN_CAP ? opt_list_cap(A) : MRT_BIN_CAP;
     static const int solo_max = getenv("MRT_CULL_SOLO") ? atoi(getenv("MRT_CULL_SOLO")) : 48;
     A.solo_max = solo_max;
     A.bin_nct_regular = A.sc.nct_regular;
@@ -1645,7 +1647,8 @@ hipError_t launch_render_cull(const RenderArgs &in, void *loose_scratch, hipStre
     uint16_t *list = (uint16_t *)((char *)loose_scratch + ((blocks * 4 + 255) / 256) * 256);
     // (MRT_LOOSE_CAP in the environment shortens the lists: stress runs use it to reach the overflow path)
     static const int cap_env = getenv("MRT_LOOSE_CAP") ? atoi(getenv("MRT_LOOSE_CAP")) : MRT_LOOSE_CAP;
-    A.loose_bx = bx; A.loose_cap = cap_env < 1 ? 1 : (cap_env > MRT_LOOSE_CAP ? MRT_LOOSE_CAP : cap_env);
+    const int cap = opt_list_cap(A) > 0 ? opt_list_cap(A) : cap_env;
+    A.loose_bx = bx; A.loose_cap = cap < 1 ? 1 : (cap > MRT_LOOSE_CAP ? MRT_LOOSE_CAP : cap);
     A.loose_nct_walk = A.sc.nct_regular; A.loose_nsct_walk = (A.sc.nct_regular + 63) / 64;
     // the padded block's largest offset from its centre ray (as launch_cull does for a tile), in double, rounded up
     const double hw = (0.5 * LOOSE_BLOCK + 0.5) / A.W, hh = (0.5 * LOOSE_BLOCK + 0.5) / A.H;

@@ -91,7 +91,7 @@ struct RenderArgs {
   float cone_ext;                   // cull kernel: max |ray - tile centre ray| over a padded tile (launcher)
   int32_t tile_map;                 // cull kernel: 0 tiles in row order (2-D grid), n: XCD-aware blocks of 2^n x 2^n tiles (1-D grid)
   const uint32_t *block_order;      // with tile_map: the blocks in the order they are to start (heaviest first), or null: as numbered
-  int32_t team_mode;                // cull kernel, MRT_OPT_CULL_TEAM: 0 automatic, 1 one wave per tile, 4 teams dealing leaves, 5 dealing lights
+  int32_t team_mode;                // launcher options (opt_team / opt_lists / opt_list_cap below); MRT_OPT_CULL_TEAM: 0 automatic, 1 one wave per tile, 4 teams dealing leaves, 5 dealing lights
   // diffuse bounces (mrt_bounce.hip, mrt_rng.hip): xorshift words of pixel i at rng[k * rng_stride + i], k = 0..4,
   // and the Weyl counter every stream starts with; null when no stream is needed
   const uint32_t *rng;
@@ -117,6 +117,13 @@ struct RenderArgs {
   int32_t bin_clusters;                 // 0: the lists hold primitives; 1: leaf clusters of 64 (scenes of more primitives than tiles)
   int32_t solo_max;                     // teams dealing leaves: a tile with at most this many batches listed is rendered by member 0 alone
 };
+// (SmallArgs below is at the 4 KB limit of a kernel's arguments, so the launcher-only options share team_mode's word:
+// bits 0-7 MRT_OPT_CULL_TEAM; bits 8-9 MRT_OPT_LISTS, 0 by the scene, 1 no lists at all (every tile walks), 2 lists of
+// primitives, 3 lists of leaf clusters; bits 16-30 MRT_OPT_LIST_CAP, > 0 (test hook) shortens every list to reach the
+// overflow paths)
+inline int opt_team(const RenderArgs &A) { return A.team_mode & 0xff; }
+inline int opt_lists(const RenderArgs &A) { return (A.team_mode >> 8) & 3; }
+inline int opt_list_cap(const RenderArgs &A) { return (A.team_mode >> 16) & 0x7fff; }
 
 hipError_t launch_render_cull(const RenderArgs &args, hipStream_t stream);
 // per-frame scratch of the loose triangles' block lists (device; loose_scratch_bytes() of it, or null = no lists)

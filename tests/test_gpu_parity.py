@@ -609,6 +609,46 @@ def test_many_cluster_scenes_depth_bounds_and_teams(gpu_ctx, kernel_mode, seed, 
     assert_stats_parity(g["stats"], ref["stats"])
 
 
+@pytest.mark.parametrize("team", [1, 4])
+@pytest.mark.parametrize("lists,cap", [(1, 0), (2, 0), (2, 3), (3, 0), (3, 2)])
+@pytest.mark.parametrize("seed,shift,spp,part", [(7, 0.0, 1, (0, 1, 8)), (1271, 1e5, 1, (0, 1, 8)), (33, 0.0, 1, (1, 3, 16)),
+                                                 (58, 0.0, 121, (0, 1, 8))])
+def test_tile_lists_of_primitives_and_of_leaf_clusters(gpu_ctx, kernel_mode, seed, shift, spp, part, lists, cap, team):
+    """Where the tiles' primary candidates come from (MRT_OPT_LISTS): the hierarchy walk, per-tile lists of primitives
+    (bin_primitives_kernel + bin_blocks_kernel), per-tile lists of leaf clusters, per-block lists of the loose triangles
+    -- and, with the lists shortened to a few entries (MRT_OPT_LIST_CAP), the overflow paths (a tile whose list
+    overflowed walks; a block whose loose list overflowed takes every loose triangle).  Thousands of primitives on a
+    small frame, ragged, in strips of a partition, at 121 samples, far from the world origin, with one wave per tile and
+    with teams dealing leaves (whose cheap tiles are rendered by one member alone when lists say how much work there
+    is): against brute force, bit for bit, counters included."""
+    if kernel_mode != "cull":
+        pytest.skip("one comparison: brute force against the tile-culling kernel")
+    sys_path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools")
+    import sys
+    if sys_path not in sys.path:
+        sys.path.insert(0, sys_path)
+    from stress_common import moved
+    spec = moved(_random_scene(seed, 200, 4000), shift, 1.0)
+    W, H = (72, 44) if spp > 1 else (203, 149)
+    gpu_ctx.upload(spec.flatten())
+    cam = spec.cam12(W / H)
+    kw = dict(spp=spp, rank=part[0], num_ranks=part[1], strip_rows=part[2])
+    gpu_ctx.set_cull(0)
+    ref = gpu_ctx.render(cam, W, H, **kw)
+    gpu_ctx.set_cull(2)
+    gpu_ctx.set_cull_team(team)
+    gpu_ctx.set_lists(lists, cap)
+    try:
+        g = gpu_ctx.render(cam, W, H, **kw)
+    finally:
+        gpu_ctx.set_cull_team(0)
+        gpu_ctx.set_lists(0, 0)
+    for k in ("id", "t", "rgb"):
+        assert np.array_equal(g[k], ref[k], equal_nan=True), (k, int((g[k] != ref[k]).sum()))
+    if part[1] == 1:
+        assert_stats_parity(g["stats"], ref["stats"])
+
+
 @pytest.mark.parametrize("team", [4, 5])
 @pytest.mark.parametrize("seed,lights", [(7, None), (21, 9)])
 def test_team_kernels_at_121_samples(gpu_ctx, kernel_mode, seed, lights, team):

@@ -5,7 +5,8 @@ wild (any sixth argument): per seed, also one of: extreme field of view, camera 
 eight decades, degenerate triangles (repeated or collinear vertices), a NaN or an infinity in the geometry.
 shift / scale: the whole scene (geometry, point lights, camera) is scaled and then moved by shift * (0.6, -0.4, 1)
 -- far from the world origin fp32 positions get coarse, which is what the culling margins have to survive.
-Environment: MRT_CULL_TEAM=4 renders every large scene with teams of four waves per tile (mrt_cull.hip) dealing leaves,
+Environment: STRESS_LISTS=1 also renders every large / huge scene with each source of primary candidates (MRT_OPT_LISTS 1, 2,
+3) and with lists shortened to a few entries (MRT_OPT_LIST_CAP: the overflow paths); MRT_CULL_TEAM=4 renders every large scene with teams of four waves per tile (mrt_cull.hip) dealing leaves,
 MRT_CULL_TEAM=5 with teams dealing lights."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -59,13 +60,19 @@ for seed in range(first, first + count):
                       {k: int((~((ref[k] == r[k]) | (np.isnan(ref[k]) & np.isnan(r[k])))).sum()) for k in ("id", "t", "rgb")}, flush=True)
         # mode 5 three times over: from the second repeat of a view the small-scene launcher starts the frame at the row
         # where the geometry begins (mrt_small.hip, small_first_row), and the order must not show
-        for mode in ((5, 5, 5, 2) if kind == "small" else (2,)):
+        runs = [(m, 0, 0) for m in ((5, 5, 5, 2) if kind == "small" else (2,))]
+        if kind != "small" and os.environ.get("STRESS_LISTS"):
+            cap = int(rng.integers(1, 9))
+            runs += [(2, 1, 0), (2, 2, 0), (2, 3, 0), (2, 2, cap), (2, 3, cap)]
+        for mode, lists, cap in runs:
+            ctx.set_lists(lists, cap)
             ctx.set_cull(mode); g = ctx.render(cam, W, H, spp=spp, rank=part[0], num_ranks=part[1], strip_rows=part[2])
+            ctx.set_lists(0, 0)
             ok = all(np.array_equal(g[k], ref[k], equal_nan=True) for k in ("id", "t", "rgb")) and \
                  all(g["stats"][k] == ref["stats"][k] for k in ("primary_rays", "shadow_rays", "hit_pixels", "occluded"))
             if not ok:
                 bad += 1
-                print("MISMATCH seed", seed, kind, "mode", mode, W, H, spp,
+                print("MISMATCH seed", seed, kind, "mode", mode, "lists", lists, cap, W, H, spp,
                       {k: int((g[k] != ref[k]).sum()) for k in ("id", "t", "rgb")}, flush=True)
     if (seed - first) % 50 == 49:
         print("seed", seed, "done, mismatches so far", bad, "%.0fs" % (time.time() - t0), flush=True)
