@@ -409,9 +409,10 @@ def measure(env, name, headline):
         m2 = statistics.median(w2)
         first_view = {"kernel_ms": round(statistics.median(k2), 5), "ms_per_step": round(m2 / steps * 1e3, 5),
                       "value": round(rays_per_frame * steps / m2 / 1e6, 3),
-                      "what": "MRT_OPT_VIEW_CACHE 0: the launch starts at tile row 0, as for a view never rendered "
-                              "before or a camera that moves every frame; the headline renders ONE view again and "
-                              "again and the launcher starts it where the geometry begins (DESIGN.md 5.5)"}
+                      "what": "MRT_OPT_VIEW_CACHE 0: every frame is launched as the first of its view, as for a camera "
+                              "that moves every frame -- the launcher works out the tile row the launch starts with "
+                              "from an estimate that costs the host microseconds (small_first_row_fast), on every "
+                              "frame; the headline renders ONE view again and again and keeps the row (DESIGN.md 5.5)"}
 
     # N > 1: is the frame that arrived on rank 0 the frame one GPU renders?  Outside the timed region: one more
     # distributed frame, then rank 0 renders all of it alone and compares the planes that travelled bit for bit.

@@ -146,10 +146,11 @@ const char *mrt_status_string(int status);
  * tile's lights (scenes with many lights).  Identical buffers in every mode.
  * MRT_OPT_FAIL_NEXT_UPLOAD (test hook; value 1) makes the next mrt_scene_upload of the context fail at its
  * device allocation, after the old scene has been given up: the context must then report MRT_ERR_NO_SCENE.
- * MRT_OPT_VIEW_CACHE (no reference counterpart; default 1): the small-scene kernel's launcher remembers the last view
- * (camera + frame size) and, when the same view is rendered again, starts the launch at the tile row where the
- * geometry begins (a scheduling choice: identical buffers).  0 = every render is treated as the first of its view,
- * which is what a camera that moves every frame gets anyway (bench.py reports that time as first_view_ms).
+ * MRT_OPT_VIEW_CACHE (no reference counterpart; default 1): the small-scene kernel's launcher starts the launch at the
+ * tile row where the view's geometry begins (a scheduling choice: identical buffers), which it works out on the host
+ * for every new view (camera + frame size; a few microseconds) and remembers while the same view is rendered again.
+ * 0 = no memory: every render is treated as the first of its view, which is what a camera that moves every frame
+ * gets anyway (bench.py reports that time as first_view_ms).
  * MRT_OPT_LISTS (no reference counterpart; default 0): where the tile-culling kernel's tiles get the candidates of their
  * primary rays from -- 0 = by the scene (per-tile lists of primitives from 2 048 primitives on when there are fewer
  * primitives than tiles, lists of 64-primitive leaf clusters when there are more, per-block lists of the loose

@@ -139,7 +139,7 @@ struct SmallViewCache {
   struct Key { DevCamera cam; int W, H, local_rows, P, lx, partitioned; } key;
   bool valid = false;
   int seen = 0;   // renders of this view so far
-  int row0 = 0;   // first tile row to launch (0 until the view has been seen twice)
+  int row0 = 0;   // first tile row to launch (small_first_row_fast, worked out when the view is first seen)
 };
 struct SmallHost {
   SmallViewCache *view = nullptr; // optional

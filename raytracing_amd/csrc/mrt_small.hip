@@ -22,8 +22,8 @@
 //     hit point p meets the plane is affine in p, for directional and for point lights, and is bounded over
 //     the ball around the tile's hit points; these functions depend on scene and lights only and are built
 //     at upload (mrt_scene_build.h, shadow_functions);
-//   * a wave is one workgroup; rows of tiles are launched starting where a view's geometry begins once the view has
-//     been seen before (small_first_row), and a tile no ray of which can hit anything takes a sky-only path;
+//   * a wave is one workgroup; rows of tiles are launched starting where the view's geometry begins (small_first_row_fast,
+//     on the host, per new view), and a tile no ray of which can hit anything takes a sky-only path;
 //   * u = col / W and v = row / H come from two tables computed once per frame size with the same IEEE
 //     division (uv_table_kernel) instead of 1 + P divisions per lane.
 //
@@ -920,10 +920,11 @@ void small_prepare_args(const RenderArgs &in, const SmallHost &hs, int P, SmallA
 // live twice as long and the frame ends when the last of them does.
 static int small_tiles_per_wave() { return MRT_SMALL_TPW_DEFAULT; }
 
-// The tile row the launch starts with (the kernel wraps around).  Decided from the view itself, on the host, with the
-// kernel's own per-tile tests (S.prm) -- 16 200 tiles x 10 primitives for the default frame, a few hundred
-// microseconds -- so only for a view that is being rendered AGAIN (SmallViewCache): the first render of a view, and
-// every render of a camera that moves each frame, starts at row 0 and pays nothing.  Rule: skip the leading rows that
+// The tile row the launch starts with (the kernel wraps around).  Decided from the view itself, on the host.  This is
+// the rule as it was first built and measured, with the kernel's own per-tile tests (S.prm) -- 16 200 tiles x 10
+// primitives for the default frame, a few hundred microseconds, which only a view that is rendered AGAIN could afford;
+// round 3 put small_first_row_fast (below) in its place for every new view and keeps this one as its yardstick
+// (MRT_SMALL_ROW0_DEBUG).  Rule: skip the leading rows that
 // hold less than 2 % of the frame's candidate tiles, keep a margin of 1/20 of the rows before the geometry begins
 // (measured on the default frame, whose geometry begins in row 28 of 135: start rows 20-26 15.7-15.9 us, 0: 16.5,
 // 28: 16.4, 30: 16.9 -- the rows skipped run LAST, and a candidate tile that starts last is a tail).  Results do
@@ -968,22 +969,84 @@ static int small_first_row(const SmallArgs &S, int ns, int nt, int P, int lx, in
   return first > margin ? first - margin : 0;
 }
 
+// The same rule from an ESTIMATE of the rows' candidate counts that costs microseconds instead of hundreds of them, so
+// that the first render of a view -- and every render of a camera that moves each frame -- gets the tuned start row
+// too.  Per sampled row of tiles and primitive, the columns whose tile centre passes the primitive's test are an
+// interval: for a sphere the u side of its screen rectangle, for a triangle the intersection of the four half-planes
+// W0' + um Wh + vm Wv >= 0 at the row's vm (one division each).  The row's count is the sum of the intervals' lengths
+// (tiles under several primitives count several times: the rule only compares counts).  At most 256 rows are sampled;
+// no heap (this also runs inside mrt_render_device_static).
+static int small_first_row_fast(const SmallArgs &S, int ns, int nt, int P, int lx, int tiles_x, int tiles_y)
+{
+  const int TW = lx * P, LY = 64 / lx;
+  const float rw = 1.0f / float(S.A.W), rh = 1.0f / float(S.A.H);
+  const float um0 = 0.5f * float(TW - 1) * rw, dum = float(TW) * rw, inv_dum = 1.0f / dum; // um(x) = um0 + x dum
+  const int ys = (tiles_y + 255) / 256;
+  float cnt[256];
+  int nrow = 0;
+  auto columns = [&](float ulo, float uhi) { // tile columns whose centre lies in [ulo, uhi]
+    if (!(ulo <= uhi)) return 0.0f;          // (empty, or NaN)
+    float xlo = std::ceil((ulo - um0) * inv_dum), xhi = std::floor((uhi - um0) * inv_dum);
+    xlo = xlo > 0.0f ? xlo : 0.0f;
+    xhi = xhi < float(tiles_x - 1) ? xhi : float(tiles_x - 1);
+    return xhi >= xlo ? xhi - xlo + 1.0f : 0.0f;
+  };
+  double total = 0.0;
+  for (int y = 0; y < tiles_y && nrow < 256; y += ys) {
+    const float vm = (float(y * LY) + 0.5f * float(LY - 1)) * rh;
+    float c = 0.0f;
+    for (int i = 0; i < ns; ++i)
+      if (!(vm < S.prm[2][i]) && !(vm > S.prm[3][i])) c += columns(S.prm[0][i], S.prm[1][i]);
+    for (int j = ns; j < ns + nt; ++j) {
+      float ulo = -INFINITY, uhi = INFINITY;
+      for (int i = 0; i < 4; ++i) {
+        const float a = S.prm[3 * i + 1][j], b = std::fmaf(vm, S.prm[3 * i + 2][j], S.prm[3 * i][j]);
+        if (a > 0.0f) ulo = std::fmax(ulo, -b / a);
+        else if (a < 0.0f) uhi = std::fmin(uhi, -b / a);
+        else if (b < 0.0f) uhi = -INFINITY; // the function does not depend on u and culls the whole row (NaN: never culls)
+      }
+      c += columns(ulo, uhi);
+    }
+    cnt[nrow++] = c;
+    total += c;
+  }
+  if (!(total > 0.0)) return 0;
+  double cum = 0.0;
+  int first = 0;
+  for (; first < nrow; ++first) {
+    cum += cnt[first];
+    if (cum * 100.0 > total) break; // more than 1 % of the (estimated) candidate tiles lie in the sampled rows up to this one
+  }
+  first *= ys;
+  // (tiles under several primitives weigh more here than in the per-tile count, which moves the threshold row down the
+  // frame by a few rows on the default view: a lower threshold and a wider margin than the per-tile rule's 2 % and 1/20)
+  const int margin = tiles_y / 16 > 2 ? tiles_y / 16 : 2;
+  return first > margin ? first - margin : 0;
+}
+
 static int small_row0(const SmallArgs &S, const SmallHost &hs, int P, int lx, int tiles_x, int tiles_y, bool partitioned)
 {
   static const int forced = [] { const char *e = getenv("MRT_SMALL_ROW0"); return e ? atoi(e) : -1; }();
   if (forced >= 0) return forced % tiles_y;
   SmallViewCache *vc = hs.view;
-  if (!vc || partitioned || tiles_y < 16) return 0; // strips of a partitioned frame are dealt over the ranks as they are
+  if (partitioned || tiles_y < 16) return 0; // strips of a partitioned frame are dealt over the ranks as they are
+  if (!vc) return small_first_row_fast(S, hs.ns, hs.nt, P, lx, tiles_x, tiles_y); // no memory of views: every render is a first one
   SmallViewCache::Key k;
   std::memset(&k, 0, sizeof k);
   k.cam = S.A.cam; k.W = S.A.W; k.H = S.A.H; k.local_rows = S.A.local_rows; k.P = P; k.lx = lx; k.partitioned = 0;
+  static const int dbg = getenv("MRT_SMALL_ROW0_DEBUG") ? atoi(getenv("MRT_SMALL_ROW0_DEBUG")) : 0; // 1: print both rules' rows; 2: use the exact rule
   if (vc->valid && std::memcmp(&k, &vc->key, sizeof k) == 0) {
-    if (++vc->seen == 2) vc->row0 = small_first_row(S, hs.ns, hs.nt, P, lx, tiles_x, tiles_y);
-    if (vc->seen > (1 << 30)) vc->seen = 1 << 30;
+    if (vc->seen < (1 << 30)) ++vc->seen;
+    if (dbg == 2 && vc->seen == 2) vc->row0 = small_first_row(S, hs.ns, hs.nt, P, lx, tiles_x, tiles_y);
     return vc->row0 < tiles_y ? vc->row0 : 0;
   }
-  vc->key = k; vc->valid = true; vc->seen = 1; vc->row0 = 0;
-  return 0;
+  // a view not seen before: the estimate (microseconds); rendered again, the view keeps its row
+  vc->key = k; vc->valid = true; vc->seen = 1;
+  vc->row0 = small_first_row_fast(S, hs.ns, hs.nt, P, lx, tiles_x, tiles_y);
+  if (dbg == 1)
+    fprintf(stderr, "[mrt] start row: estimate %d, per-tile rule %d (of %d rows)\n", vc->row0,
+            small_first_row(S, hs.ns, hs.nt, P, lx, tiles_x, tiles_y), tiles_y);
+  return vc->row0 < tiles_y ? vc->row0 : 0;
 }
 
 template <int P>

@@ -20,7 +20,7 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
             W, H = (3840, 2160) if cfg in ("C3", "C4", "C4m") else (1920, 1080)
             flat = spec.flatten(); cam12 = spec.cam12(W / H)
     fr = multigpu.FrameRenderer(flat, cam12, W, H, **({"spp": 121, "max_depth": 8} if cfg == "REF" else {}))
-    n = 400 if cfg == "C2" else 5
+    n = 400 if cfg == "C2" else (40 if cfg in ("C3", "C5") else 10)
     best = None
     for rep in range(3):   # HIP events around n back-to-back launches; best of three
         for _ in range(max(2, n // 10)): fr.render_local()
