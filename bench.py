@@ -507,7 +507,7 @@ def measure(env, name, headline):
                          "traffic_stale": stale if traffic is not None else None,
                          "kernel": kernel_name, "kernel_ms": round(kern_ms, 5), "kernel_ms_how": kern_how,
                          "algorithmic_bytes_per_launch": alg_bytes,
-                         "binding_resource": "vector-instruction issue, not HBM (see executed_work; DESIGN.md 5.5)"},
+                         "binding_resource": "vector-instruction issue, not HBM (see executed_work.valu_issue_measured_costs; DESIGN.md 5.5)"},
         }
         if world > 1:
             out["multi_gpu"] = {**multi, "exchange_overlaps_next_render": multi["pipeline_depth"] > 1,
@@ -522,6 +522,27 @@ def measure(env, name, headline):
                   "valu_issue_ms": round(issue_ms, 5),
                   "valu_issue_frac_of_kernel_time": round(issue_ms / kern_ms, 4),
                   "valu_issue_model": "SQ_INSTS_VALU / 1024 SIMDs x 2 cycles at 2.4 GHz (MI355X_MICROARCH.md)"}
+            mixk = ("SQ_INSTS_VALU_ADD_F32", "SQ_INSTS_VALU_MUL_F32", "SQ_INSTS_VALU_FMA_F32", "SQ_INSTS_VALU_TRANS_F32",
+                    "SQ_INSTS_VALU_INT32", "SQ_INSTS_VALU_CVT")
+            if all(k in pmc for k in mixk):
+                # The 2-cycle model above prices every vector instruction as a plain multiply.  tools/ubench_mix.hip
+                # measured what the kinds really cost per SIMD with 8 waves resident (ns per instruction): v_mul / v_add /
+                # integer add 1.15, v_fma 1.68, v_rcp / v_sqrt / v_rsq and v_readlane 3.45, conversions 1.8, compares,
+                # selects, min / max, DPP moves and the pieces of IEEE division 1.85-2.0, plain moves 0.98.  With the
+                # kernel's own mix (counter pass sq3) that gives its issue time; "other" (everything the typed counters
+                # do not name: moves, compares, selects, min / max, lane reads and writes, DPP, division pieces) is priced
+                # at 1.8 and, as a floor, at 0.98 as if it were all moves.
+                add, mul, fma, trans, i32, cvt = (pmc[k] for k in mixk)
+                other = max(0.0, valu - (add + mul + fma + trans + i32 + cvt))
+                typed_ns = (add + mul) * 1.15 + fma * 1.68 + trans * 3.45 + i32 * 1.2 + cvt * 1.8
+                est_ms, low_ms = (typed_ns + other * 1.8) / SIMDS * 1e-6, (typed_ns + other * 0.98) / SIMDS * 1e-6
+                ex["valu_issue_measured_costs"] = {
+                    "ms": round(est_ms, 5), "frac_of_kernel_time": round(est_ms / kern_ms, 4),
+                    "floor_ms": round(low_ms, 5), "floor_frac_of_kernel_time": round(low_ms / kern_ms, 4),
+                    "mix": {"add_f32": int(add), "mul_f32": int(mul), "fma_f32": int(fma), "trans_f32": int(trans),
+                            "int32": int(i32), "cvt": int(cvt), "other": int(other)},
+                    "how": "per-kind instruction counts (SQ_INSTS_VALU_*) x the per-kind issue costs measured by "
+                           "tools/ubench_mix.hip (profiles/r03_ubench_mix.txt), over 1024 SIMDs"}
             if pmc.get("rocprof_kernel_avg_ns"):
                 ex["rocprof_kernel_avg_ms"] = round(pmc["rocprof_kernel_avg_ns"] * 1e-6, 5)
             if "SQ_WAVES" in pmc:

@@ -99,13 +99,13 @@ __device__ __forceinline__ TileCone make_tile_cone(const DevCamera &cam, int W, 
   TileCone t;
   const float rw = fast_rcp(float(W)), rh = fast_rcp(float(H)); // bound arithmetic: approximate is fine
   const float um = (float(tile_x * TW) + 0.5f * float(TW - 1)) * rw, vm = (float(grow0) + 3.5f) * rh;
-  t.dcx = ((cam.ux + um * cam.hx) + vm * cam.vx) - cam.ox;
-  t.dcy = ((cam.uy + um * cam.hy) + vm * cam.vy) - cam.oy;
-  t.dcz = ((cam.uz + um * cam.hz) + vm * cam.vz) - cam.oz;
-  const float inv = fast_rsq(dot3(t.dcx, t.dcy, t.dcz, t.dcx, t.dcy, t.dcz));
+  t.dcx = __builtin_fmaf(vm, cam.vx, __builtin_fmaf(um, cam.hx, cam.ux)) - cam.ox;
+  t.dcy = __builtin_fmaf(vm, cam.vy, __builtin_fmaf(um, cam.hy, cam.uy)) - cam.oy;
+  t.dcz = __builtin_fmaf(vm, cam.vz, __builtin_fmaf(um, cam.hz, cam.uz)) - cam.oz;
+  const float inv = fast_rsq(bdot3(t.dcx, t.dcy, t.dcz, t.dcx, t.dcy, t.dcz));
   t.cax = t.dcx * inv; t.cay = t.dcy * inv; t.caz = t.dcz * inv;
-  t.sinT = cone_ext * inv * (1.0f + 1e-4f) + 1e-6f;
-  t.cosT = fast_sqrt(fmaxf(1.0f - t.sinT * t.sinT, 0.0f)) * (1.0f - 1e-5f) - 1e-6f;
+  t.sinT = __builtin_fmaf(cone_ext * inv, 1.0f + 1e-4f, 1e-6f);
+  t.cosT = __builtin_fmaf(fast_sqrt(fmaxf(__builtin_fmaf(-t.sinT, t.sinT, 1.0f), 0.0f)), 1.0f - 1e-5f, -1e-6f);
   // a cone of 90 degrees or more (or a NaN camera) cannot cull: cos = -1 makes every ball pass
   if (!(t.sinT < 0.99f) || !(t.cosT > 0.0f)) { t.cosT = -1.0f; t.sinT = 0.0f; }
   return t;
@@ -159,12 +159,13 @@ __device__ __forceinline__ bool triangle_may_be_hit(const DevScene &sc, const De
     const float pnx = AOS ? field(0) : sc.tri[i], pny = AOS ? field(1) : sc.tri[snt + i], pnz = AOS ? field(2) : sc.tri[2 * snt + i],
                 kp = AOS ? field(3) : sc.tri[3 * snt + i];
     const float num = kp - dot3(cam.ox, cam.oy, cam.oz, pnx, pny, pnz);
-    const float c = dot3(pnx, pny, pnz, C.cax, C.cay, C.caz);
-    const float qx = pnx - c * C.cax, qy = pny - c * C.cay, qz = pnz - c * C.caz;
-    const float sp = fast_sqrt(dot3(qx, qy, qz, qx, qy, qz));
+    const float c = bdot3(pnx, pny, pnz, C.cax, C.cay, C.caz);
+    const float qx = __builtin_fmaf(-c, C.cax, pnx), qy = __builtin_fmaf(-c, C.cay, pny), qz = __builtin_fmaf(-c, C.caz, pnz);
+    const float sp = fast_sqrt(bdot3(qx, qy, qz, qx, qy, qz));
     const float pn1 = norm1(pnx, pny, pnz);
     const float slack = 2e-5f * pn1;
-    const float lo = c * C.cosT - sp * C.sinT - slack, hi = c * C.cosT + sp * C.sinT + slack;
+    const float ccos = c * C.cosT;
+    const float lo = __builtin_fmaf(-sp, C.sinT, ccos) - slack, hi = __builtin_fmaf(sp, C.sinT, ccos) + slack;
     if (C.cosT > 0.0f && (lo > 0.0f || hi < 0.0f)) { // (C.cosT = -1: the cone cannot cull)
       // max |n.u| over the cone: cos(phi - theta) for a normal at angle phi >= theta from the axis -- but a normal
       // INSIDE the cone (phi < theta: a wall seen head-on, or any normal once rounding has widened the cone far
@@ -184,10 +185,10 @@ __device__ __forceinline__ bool triangle_may_be_hit(const DevScene &sc, const De
         for (int e = 0; e < 3; ++e) {
           const float mx = AOS ? field(4 + 4 * e) : sc.tri[(4 + 4 * e) * snt + i], my = AOS ? field(5 + 4 * e) : sc.tri[(5 + 4 * e) * snt + i],
                       mz = AOS ? field(6 + 4 * e) : sc.tri[(6 + 4 * e) * snt + i], ce = AOS ? field(7 + 4 * e) : sc.tri[(7 + 4 * e) * snt + i];
-          const float a = dot3(mx, my, mz, cam.ox, cam.oy, cam.oz) - ce;
-          const float wx = a * pnx + num * mx, wy = a * pny + num * my, wz = a * pnz + num * mz;
-          const float top = sgn * dot3(wx, wy, wz, C.dcx, C.dcy, C.dcz) + fabsf(dot3(wx, wy, wz, C.ehx, C.ehy, C.ehz)) +
-                            fabsf(dot3(wx, wy, wz, C.evx, C.evy, C.evz));
+          const float a = bdot3(mx, my, mz, cam.ox, cam.oy, cam.oz) - ce;
+          const float wx = __builtin_fmaf(a, pnx, num * mx), wy = __builtin_fmaf(a, pny, num * my), wz = __builtin_fmaf(a, pnz, num * mz);
+          const float top = sgn * bdot3(wx, wy, wz, C.dcx, C.dcy, C.dcz) + fabsf(bdot3(wx, wy, wz, C.ehx, C.ehy, C.ehz)) +
+                            fabsf(bdot3(wx, wy, wz, C.evx, C.evy, C.evz));
           const float m1 = norm1(mx, my, mz);
           // How far can the exact test's fp32 e_i |n.d| be from w_i.d as computed here?  First-order rounding
           // analysis of both (u = 2^-24 per operation, 1-norms for the sums):
@@ -205,11 +206,14 @@ __device__ __forceinline__ bool triangle_may_be_hit(const DevScene &sc, const De
 #if MRT_REFINE_MD
           // the amplified term moves p ALONG THE RAY, so it reaches e_i through |m.d|, not |m| |d|: bound that over
           // the padded tile (centre value + extents) instead of by norms
-          const float md = (fabsf(dot3(mx, my, mz, C.dcx, C.dcy, C.dcz)) + fabsf(dot3(mx, my, mz, C.ehx, C.ehy, C.ehz)) +
-                            fabsf(dot3(mx, my, mz, C.evx, C.evy, C.evz))) * 1.001f;
-          const float err = MRT_REFINE_U * (dl * m1 * (8.0f * N1 + 7.0f * fabsf(num)) + md * 3.5f * pn1 * fabsf(num) * inv_lo +
-                                            dl * ((4.0f * pn1 + 5.0f * big) * (m1 * o1 + fabsf(ce)) + 4.0f * w1)) +
-                            w1 * C.cam_round + 1e-6f * big * dl;
+          const float md = (fabsf(bdot3(mx, my, mz, C.dcx, C.dcy, C.dcz)) + fabsf(bdot3(mx, my, mz, C.ehx, C.ehy, C.ehz)) +
+                            fabsf(bdot3(mx, my, mz, C.evx, C.evy, C.evz))) * 1.001f;
+          const float anum = fabsf(num);
+          const float err = __builtin_fmaf(MRT_REFINE_U,
+                                __builtin_fmaf(dl * m1, __builtin_fmaf(7.0f, anum, 8.0f * N1),
+                                    __builtin_fmaf(md * 3.5f * pn1, anum * inv_lo,
+                                        dl * __builtin_fmaf(__builtin_fmaf(5.0f, big, 4.0f * pn1), __builtin_fmaf(m1, o1, fabsf(ce)), 4.0f * w1))),
+                                __builtin_fmaf(w1, C.cam_round, 1e-6f * big * dl));
 #else
           const float err = MRT_REFINE_U * dl * (m1 * (8.0f * N1 + fabsf(num) * (7.0f + 3.5f * pn1 * inv_lo)) +
                                                  (4.0f * pn1 + 5.0f * big) * (m1 * o1 + fabsf(ce)) + 4.0f * w1) +
@@ -357,7 +361,7 @@ void render_cull_kernel(RenderArgs A)
   // hierarchy tests against the cone: a ball of spheres / a ball of triangle bounds
   auto cone_vs_sphere_ball = [&](float x, float y, float z, float R) {
     const float wx = x - cam.ox, wy = y - cam.oy, wz = z - cam.oz;
-    const float L = fast_sqrt(dot3(wx, wy, wz, wx, wy, wz)) * CULL_REL + R;
+    const float L = __builtin_fmaf(fast_sqrt(bdot3(wx, wy, wz, wx, wy, wz)), CULL_REL, R);
     return ball_may_touch_cone(wx, wy, wz, cluster_cull_radius(R, L), cax, cay, caz, cosT, sinT);
   };
   auto cone_vs_tri_ball = [&](float x, float y, float z, float R) {
@@ -402,10 +406,9 @@ void render_cull_kernel(RenderArgs A)
     //      tile_tmax * max |d| away is skipped, as are its cluster and super-cluster.  Wave-uniform, refreshed
     //      after every leaf that moved a best_t; +inf while a pixel (inside the frame) has no hit.  Margin 1e-4
     //      (relative) against a rounding of 1e-6 in the exact tests' t and hit points. ----
-    float dlen_max = 0.0f;
-#pragma unroll
-    for (int p = 0; p < P; ++p) dlen_max = fmaxf(dlen_max, aa[p]);
-    dlen_max = fast_sqrt(wave_max(dlen_max)) * (1.0f + 1e-5f);
+    // (max |d| over the tile: every ray of the padded tile is the centre ray plus an offset of norm <= cone_ext, so
+    // |centre ray| + cone_ext bounds it without a reduction over the lanes)
+    const float dlen_max = (fast_sqrt(bdot3(dcx, dcy, dcz, dcx, dcy, dcz)) + A.cone_ext) * (1.0f + 1e-5f);
     float reach_max = MRT_INF; // tile_tmax * max |d| * (1 + 1e-4)
     auto refresh_reach = [&]() {
       float m = 0.0f;
@@ -416,8 +419,8 @@ void render_cull_kernel(RenderArgs A)
     auto sphere_ball_in_reach = [&](float x, float y, float z, float R) {
       if (!cone_vs_sphere_ball(x, y, z, R)) return false;
       const float wx = x - cam.ox, wy = y - cam.oy, wz = z - cam.oz;
-      const float L = fast_sqrt(dot3(wx, wy, wz, wx, wy, wz));
-      return !(L * (1.0f - 1e-5f) - cluster_cull_radius(R, L * CULL_REL + R) > reach_max);
+      const float L = fast_sqrt(bdot3(wx, wy, wz, wx, wy, wz));
+      return !(__builtin_fmaf(L, 1.0f - 1e-5f, -cluster_cull_radius(R, __builtin_fmaf(L, CULL_REL, R))) > reach_max);
     };
     // (Triangles get no such test on their bounding balls: far from the world origin the exact test's
     // t = (k - n.o) / (n.d) cancels catastrophically in k - n.o and is off by 1e-7 (|k| + |n||o|) / |n.d|, without
@@ -436,10 +439,10 @@ void render_cull_kernel(RenderArgs A)
       if (have) {
         cx = sc.sph_cx[i]; cy = sc.sph_cy[i]; cz = sc.sph_cz[i]; r = sc.sph_r[i];
         const float wx = cx - cam.ox, wy = cy - cam.oy, wz = cz - cam.oz;
-        const float L2 = dot3(wx, wy, wz, wx, wy, wz);
+        const float L2 = bdot3(wx, wy, wz, wx, wy, wz);
         const float reff = sphere_cull_radius(r * r, L2);
         pass = (binned || ball_may_touch_cone(wx, wy, wz, reff, cax, cay, caz, cosT, sinT)) &&
-               !(fast_sqrt(L2) * (1.0f - 1e-5f) - reff > reach_max);
+               !(__builtin_fmaf(fast_sqrt(L2), 1.0f - 1e-5f, -reff) > reach_max);
       }
       unsigned long long mask = __ballot(pass);
       n_clusters++; n_exact += __popcll(mask);
@@ -685,20 +688,16 @@ void render_cull_kernel(RenderArgs A)
       Bundle B;
       {
         if (ns + nt > 64) {
-          // many primitives: a tight ball pays for itself (centre of the hit points' box, 6 reductions)
+          // many primitives: a tight ball pays for itself.  The hit points lie along the tile's rays between the nearest and
+          // the farthest hit: centre = the tile's centre ray at the middle of that range (2 reductions; the centre of the
+          // hit points' box took 6 for a ball of the same size, and a reduction is 13 vector instructions)
           const float big = 3.0e38f;
-          float lox = big, loy = big, loz = big, hix = -big, hiy = -big, hiz = -big;
+          float tlo = big, thi = -big;
 #pragma unroll
           for (int p = 0; p < P; ++p)
-            if (have_hit[p]) {
-              lox = fminf(lox, hpx[p]); hix = fmaxf(hix, hpx[p]);
-              loy = fminf(loy, hpy[p]); hiy = fmaxf(hiy, hpy[p]);
-              loz = fminf(loz, hpz[p]); hiz = fmaxf(hiz, hpz[p]);
-            }
-          lox = wave_min(lox); hix = wave_max(hix);
-          loy = wave_min(loy); hiy = wave_max(hiy);
-          loz = wave_min(loz); hiz = wave_max(hiz);
-          B.mx = 0.5f * (lox + hix); B.my = 0.5f * (loy + hiy); B.mz = 0.5f * (loz + hiz);
+            if (have_hit[p]) { tlo = fminf(tlo, best_t[p]); thi = fmaxf(thi, best_t[p]); }
+          const float tmid = 0.5f * (wave_min(tlo) + wave_max(thi));
+          B.mx = __builtin_fmaf(tmid, dcx, cam.ox); B.my = __builtin_fmaf(tmid, dcy, cam.oy); B.mz = __builtin_fmaf(tmid, dcz, cam.oz);
         } else {
           // few primitives: centre = the first hit point found (1 reduction)
           float mx = 0.0f, my = 0.0f, mz = 0.0f;
@@ -718,13 +717,13 @@ void render_cull_kernel(RenderArgs A)
 #pragma unroll
         for (int p = 0; p < P; ++p) {
           const float ex = hpx[p] - B.mx, ey = hpy[p] - B.my, ez = hpz[p] - B.mz;
-          e2 = fmaxf(e2, have_hit[p] ? dot3(ex, ey, ez, ex, ey, ez) : 0.0f);
+          e2 = fmaxf(e2, have_hit[p] ? bdot3(ex, ey, ez, ex, ey, ez) : 0.0f);
         }
         B.rho = fast_sqrt(wave_max(e2)) * CULL_REL + CULL_ABS;
       }
       auto bundle_vs_sphere_ball = [&](float x, float y, float z, float R) {
         const float wx = x - B.mx, wy = y - B.my, wz = z - B.mz;
-        const float Lm = fast_sqrt(dot3(wx, wy, wz, wx, wy, wz)) * CULL_REL + B.rho + R;
+        const float Lm = __builtin_fmaf(fast_sqrt(bdot3(wx, wy, wz, wx, wy, wz)), CULL_REL, B.rho + R);
         return bundle_may_touch(B, x, y, z, cluster_cull_radius(R, Lm));
       };
       auto bundle_vs_tri_ball = [&](float x, float y, float z, float R) { return bundle_may_touch(B, x, y, z, R); };
@@ -760,9 +759,9 @@ void render_cull_kernel(RenderArgs A)
         for (int p = 0; p < P; ++p)
           if (have_hit[p]) {
             const float ex = hpx[p] - B.mx, ey = hpy[p] - B.my, ez = hpz[p] - B.mz;
-            ea = fmaxf(ea, fabsf(dot3(cax, cay, caz, ex, ey, ez)));
-            e1 = fmaxf(e1, fabsf(dot3(fb1x, fb1y, fb1z, ex, ey, ez)));
-            e2 = fmaxf(e2, fabsf(dot3(fb2x, fb2y, fb2z, ex, ey, ez)));
+            ea = fmaxf(ea, fabsf(bdot3(cax, cay, caz, ex, ey, ez)));
+            e1 = fmaxf(e1, fabsf(bdot3(fb1x, fb1y, fb1z, ex, ey, ez)));
+            e2 = fmaxf(e2, fabsf(bdot3(fb2x, fb2y, fb2z, ex, ey, ez)));
           }
         fEa = wave_max(ea); fE1 = wave_max(e1); fE2 = wave_max(e2);
       }
@@ -793,18 +792,18 @@ void render_cull_kernel(RenderArgs A)
           if (!Bl.point) { Bl.Dx = -lvx; Bl.Dy = -lvy; Bl.Dz = -lvz; }
           else { Bl.Dx = lvx - B.mx; Bl.Dy = lvy - B.my; Bl.Dz = lvz - B.mz; }
         }
-        Bl.DD = dot3(Bl.Dx, Bl.Dy, Bl.Dz, Bl.Dx, Bl.Dy, Bl.Dz);
+        Bl.DD = bdot3(Bl.Dx, Bl.Dy, Bl.Dz, Bl.Dx, Bl.Dy, Bl.Dz);
         {
-          float nx = cay * Bl.Dz - caz * Bl.Dy, ny = caz * Bl.Dx - cax * Bl.Dz, nz = cax * Bl.Dy - cay * Bl.Dx;
-          const float nn = dot3(nx, ny, nz, nx, ny, nz);
+          float nx = __builtin_fmaf(cay, Bl.Dz, -(caz * Bl.Dy)), ny = __builtin_fmaf(caz, Bl.Dx, -(cax * Bl.Dz)), nz = __builtin_fmaf(cax, Bl.Dy, -(cay * Bl.Dx));
+          const float nn = bdot3(nx, ny, nz, nx, ny, nz);
           Bl.snx = 0.0f; Bl.sny = 0.0f; Bl.snz = 0.0f; Bl.sw = MRT_INF;
           if (nn > 2.5e-3f * Bl.DD) { // as bundle_make_slab: below ~3 degrees between axis and light the normal is ill-conditioned
             const float inv = fast_rsq(nn);
             nx *= inv; ny *= inv; nz *= inv;
-            const float w = fabsf(dot3(nx, ny, nz, cax, cay, caz)) * fEa + fabsf(dot3(nx, ny, nz, fb1x, fb1y, fb1z)) * fE1 +
-                            fabsf(dot3(nx, ny, nz, fb2x, fb2y, fb2z)) * fE2;
+            const float w = __builtin_fmaf(fabsf(bdot3(nx, ny, nz, cax, cay, caz)), fEa, __builtin_fmaf(fabsf(bdot3(nx, ny, nz, fb1x, fb1y, fb1z)), fE1,
+                                 fabsf(bdot3(nx, ny, nz, fb2x, fb2y, fb2z)) * fE2));
             Bl.snx = nx; Bl.sny = ny; Bl.snz = nz;
-            Bl.sw = w * (CULL_REL * 1.001f) + CULL_ABS + (Bl.point ? 1e-5f * norm1(Bl.Dx, Bl.Dy, Bl.Dz) : 0.0f);
+            Bl.sw = __builtin_fmaf(w, CULL_REL * 1.001f, CULL_ABS) + (Bl.point ? 1e-5f * norm1(Bl.Dx, Bl.Dy, Bl.Dz) : 0.0f);
           }
         }
         bool pass = false;
@@ -817,7 +816,7 @@ void render_cull_kernel(RenderArgs A)
             const unsigned n = (unsigned)sc.ncs;
             const float x = sc.sph_clu[cu], y = sc.sph_clu[n + cu], z = sc.sph_clu[2u * n + cu], R = sc.sph_clu[3u * n + cu];
             const float wx = x - B.mx, wy = y - B.my, wz = z - B.mz;
-            const float Lm = fast_sqrt(dot3(wx, wy, wz, wx, wy, wz)) * CULL_REL + B.rho + R;
+            const float Lm = __builtin_fmaf(fast_sqrt(bdot3(wx, wy, wz, wx, wy, wz)), CULL_REL, B.rho + R);
             pass = bundle_may_touch(Bl, x, y, z, cluster_cull_radius(R, Lm));
           } else {
             const unsigned k = cu - (unsigned)sc.ncs, n = (unsigned)sc.nct;
@@ -874,11 +873,11 @@ void render_cull_kernel(RenderArgs A)
           pre_bits = 0;
 #endif
         } else {
-        B.DD = dot3(B.Dx, B.Dy, B.Dz, B.Dx, B.Dy, B.Dz);
+        B.DD = bdot3(B.Dx, B.Dy, B.Dz, B.Dx, B.Dy, B.Dz);
         {
           // slab of the bundle for this light (bundle_make_slab, here with P hit points per lane)
           float nx = cay * B.Dz - caz * B.Dy, ny = caz * B.Dx - cax * B.Dz, nz = cax * B.Dy - cay * B.Dx;
-          const float nn = dot3(nx, ny, nz, nx, ny, nz);
+          const float nn = bdot3(nx, ny, nz, nx, ny, nz);
           B.snx = 0.0f; B.sny = 0.0f; B.snz = 0.0f; B.sw = MRT_INF;
           if (nn > 2.5e-3f * B.DD) {
             const float inv = fast_rsq(nn);
@@ -886,7 +885,7 @@ void render_cull_kernel(RenderArgs A)
             float dmax = 0.0f;
 #pragma unroll
             for (int p = 0; p < P; ++p)
-              dmax = fmaxf(dmax, have_hit[p] ? fabsf(dot3(nx, ny, nz, hpx[p] - B.mx, hpy[p] - B.my, hpz[p] - B.mz)) : 0.0f);
+              dmax = fmaxf(dmax, have_hit[p] ? fabsf(bdot3(nx, ny, nz, hpx[p] - B.mx, hpy[p] - B.my, hpz[p] - B.mz)) : 0.0f);
             B.snx = nx; B.sny = ny; B.snz = nz;
             B.sw = wave_max(dmax) * CULL_REL + CULL_ABS + (B.point ? 1e-5f * norm1(B.Dx, B.Dy, B.Dz) : 0.0f);
           }
@@ -914,7 +913,7 @@ void render_cull_kernel(RenderArgs A)
             if (i < ns) {
               cx = sc.sph_cx[i]; cy = sc.sph_cy[i]; cz = sc.sph_cz[i]; r = sc.sph_r[i];
               const float wx = cx - B.mx, wy = cy - B.my, wz = cz - B.mz;
-              const float Lm = fast_sqrt(dot3(wx, wy, wz, wx, wy, wz)) * CULL_REL + B.rho; // >= |hit point - centre|
+              const float Lm = __builtin_fmaf(fast_sqrt(bdot3(wx, wy, wz, wx, wy, wz)), CULL_REL, B.rho); // >= |hit point - centre|
               pass = bundle_may_touch(B, cx, cy, cz, sphere_cull_radius(r * r, Lm * Lm));
             }
             unsigned long long mask = __ballot(pass);
@@ -1226,15 +1225,15 @@ __global__ __launch_bounds__(256) void bin_loose_kernel(RenderArgs A, float bloc
     const float du = (0.5f * float(LOOSE_BLOCK) + 0.51f) * rw * 1.001f, dv = (0.5f * float(LOOSE_BLOCK) + 0.51f) * rh * 1.001f; // pixels -1 .. 64
     C.ehx = du * cam.hx; C.ehy = du * cam.hy; C.ehz = du * cam.hz;
     C.evx = dv * cam.vx; C.evy = dv * cam.vy; C.evz = dv * cam.vz;
-    const float dd = dot3(C.dcx, C.dcy, C.dcz, C.dcx, C.dcy, C.dcz);
+    const float dd = bdot3(C.dcx, C.dcy, C.dcz, C.dcx, C.dcy, C.dcz);
     const float inv = fast_rsq(dd);
     C.cax = C.dcx * inv; C.cay = C.dcy * inv; C.caz = C.dcz * inv;
     C.sinT = block_cone_ext * inv * (1.0f + 1e-4f) + 1e-6f;
     C.cosT = fast_sqrt(fmaxf(1.0f - C.sinT * C.sinT, 0.0f)) * (1.0f - 1e-5f) - 1e-6f;
     if (!(C.sinT < 0.99f) || !(C.cosT > 0.0f)) { C.cosT = -1.0f; C.sinT = 0.0f; } // cannot cull
     // no ray of the padded block is longer than the centre ray plus the two half extents
-    C.dlen_max = (fast_sqrt(dd) + fast_sqrt(dot3(C.ehx, C.ehy, C.ehz, C.ehx, C.ehy, C.ehz)) +
-                  fast_sqrt(dot3(C.evx, C.evy, C.evz, C.evx, C.evy, C.evz))) * (1.0f + 1e-4f);
+    C.dlen_max = (fast_sqrt(dd) + fast_sqrt(bdot3(C.ehx, C.ehy, C.ehz, C.ehx, C.ehy, C.ehz)) +
+                  fast_sqrt(bdot3(C.evx, C.evy, C.evz, C.evx, C.evy, C.evz))) * (1.0f + 1e-4f);
     C.reach_max = MRT_INF;
   }
   const bool pass = i < sc.nt && triangle_may_be_hit(sc, cam, C, i);
@@ -1298,7 +1297,7 @@ __device__ __forceinline__ void bin_ball(const RenderArgs &A, int g, float &wx, 
     if (g < sc.ncs) {
       const float R = sc.sph_clu[3 * sc.ncs + g];
       wx = sc.sph_clu[g] - cam.ox; wy = sc.sph_clu[sc.ncs + g] - cam.oy; wz = sc.sph_clu[2 * sc.ncs + g] - cam.oz;
-      reff = cluster_cull_radius(R, fast_sqrt(dot3(wx, wy, wz, wx, wy, wz)) * CULL_REL + R); // as cone_vs_sphere_ball
+      reff = cluster_cull_radius(R, fast_sqrt(bdot3(wx, wy, wz, wx, wy, wz)) * CULL_REL + R); // as cone_vs_sphere_ball
     } else {
       const int k = g - sc.ncs;
       wx = sc.tri_clu[k] - cam.ox; wy = sc.tri_clu[sc.nct + k] - cam.oy; wz = sc.tri_clu[2 * sc.nct + k] - cam.oz;
@@ -1307,7 +1306,7 @@ __device__ __forceinline__ void bin_ball(const RenderArgs &A, int g, float &wx, 
   } else if (g < sc.ns) {
     const float r = sc.sph_r[g];
     wx = sc.sph_cx[g] - cam.ox; wy = sc.sph_cy[g] - cam.oy; wz = sc.sph_cz[g] - cam.oz;
-    reff = sphere_cull_radius(r * r, dot3(wx, wy, wz, wx, wy, wz)); // as sphere_batch
+    reff = sphere_cull_radius(r * r, bdot3(wx, wy, wz, wx, wy, wz)); // as sphere_batch
   } else {
     const int i = g - sc.ns;
     wx = sc.tri_bx[i] - cam.ox; wy = sc.tri_by[i] - cam.oy; wz = sc.tri_bz[i] - cam.oz;
@@ -1344,7 +1343,7 @@ __global__ __launch_bounds__(256) void bin_primitives_kernel(RenderArgs A, BinCa
   int tx0 = 0, tx1 = -1, ty0 = 0, ty1 = -1;
   bool near = live;
   if (live) {
-    const float X = dot3(wx, wy, wz, C.hx, C.hy, C.hz), Y = dot3(wx, wy, wz, C.vx, C.vy, C.vz), Z = dot3(wx, wy, wz, C.nx, C.ny, C.nz);
+    const float X = bdot3(wx, wy, wz, C.hx, C.hy, C.hz), Y = bdot3(wx, wy, wz, C.vx, C.vy, C.vz), Z = bdot3(wx, wy, wz, C.nx, C.ny, C.nz);
     const float L1 = norm1(wx, wy, wz);
     const float R = reff * 1.02f + 1e-5f * L1 + 1e-6f; // the test's slack (CULL_LEN_SLACK of |w|_1) and this block's own rounding
     if (Z > R * 1.01f + 1e-5f * L1 && R < 3.0e37f) {   // the ball lies in front of the camera plane, clear of it (NaN: near)

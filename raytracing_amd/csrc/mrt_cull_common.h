@@ -61,20 +61,28 @@ __device__ __forceinline__ void fast_normalize(float &x, float &y, float &z)
 // effective radius of a sphere of squared radius rr seen from distance <= Lmax
 __device__ __forceinline__ float sphere_cull_radius(float rr, float Lmax2)
 {
-  return fast_sqrt(rr + CULL_DISC_SLACK * Lmax2) * CULL_REL + CULL_ABS;
+  return __builtin_fmaf(fast_sqrt(__builtin_fmaf(CULL_DISC_SLACK, Lmax2, rr)), CULL_REL, CULL_ABS);
 }
 
 __device__ __forceinline__ float norm1(float x, float y, float z) { return fabsf(x) + fabsf(y) + fabsf(z); }
+
+// Bound arithmetic may fuse (the build contracts nothing by itself: -ffp-contract=off is part of the exact tests'
+// contract): a dot product as one multiply and two FMAs.  tools/ubench_mix.hip: a v_fma_f32 costs a SIMD 1.5 v_mul_f32,
+// the multiply-add pair it replaces 2.  Only for bounds -- the exact tests keep dot3().
+__device__ __forceinline__ float bdot3(float ax, float ay, float az, float bx, float by, float bz)
+{
+  return __builtin_fmaf(ax, bx, __builtin_fmaf(ay, by, az * bz));
+}
 
 // Cone {x : angle(x - apex, axis) <= theta}, |axis| = 1: true when the ball (w = centre - apex, radius reff)
 // may touch it.  dist(ball centre, cone) >= perp*cos - proj*sin (distance to the supporting half-space).
 __device__ __forceinline__ bool ball_may_touch_cone(float wx, float wy, float wz, float reff, float ax, float ay,
                                                     float az, float cosT, float sinT)
 {
-  const float proj = dot3(wx, wy, wz, ax, ay, az);
-  const float qx = wx - proj * ax, qy = wy - proj * ay, qz = wz - proj * az;
-  const float perp = fast_sqrt(dot3(qx, qy, qz, qx, qy, qz));
-  return !(perp * cosT - proj * sinT > reff + CULL_LEN_SLACK * norm1(wx, wy, wz));
+  const float proj = bdot3(wx, wy, wz, ax, ay, az);
+  const float qx = __builtin_fmaf(-proj, ax, wx), qy = __builtin_fmaf(-proj, ay, wy), qz = __builtin_fmaf(-proj, az, wz);
+  const float perp = fast_sqrt(bdot3(qx, qy, qz, qx, qy, qz));
+  return !(__builtin_fmaf(perp, cosT, -(proj * sinT)) > __builtin_fmaf(CULL_LEN_SLACK, norm1(wx, wy, wz), reff));
 }
 
 // Ray bundle {m + e + t*D : |e| <= rho, t >= 0} (directional light): true when the ball at w = centre - m may
@@ -82,10 +90,10 @@ __device__ __forceinline__ bool ball_may_touch_cone(float wx, float wy, float wz
 __device__ __forceinline__ bool ball_may_touch_sweep(float wx, float wy, float wz, float reach, float Dx, float Dy,
                                                      float Dz, float DD)
 {
-  const float s = fmaxf(dot3(wx, wy, wz, Dx, Dy, Dz) * fast_rcp(DD), 0.0f); // behind the origin: distance to m
-  const float qx = wx - s * Dx, qy = wy - s * Dy, qz = wz - s * Dz;
-  const float dist = fast_sqrt(dot3(qx, qy, qz, qx, qy, qz));
-  return !(dist > reach + CULL_LEN_SLACK * (norm1(wx, wy, wz) + s * norm1(Dx, Dy, Dz)));
+  const float s = fmaxf(bdot3(wx, wy, wz, Dx, Dy, Dz) * fast_rcp(DD), 0.0f); // behind the origin: distance to m
+  const float qx = __builtin_fmaf(-s, Dx, wx), qy = __builtin_fmaf(-s, Dy, wy), qz = __builtin_fmaf(-s, Dz, wz);
+  const float dist = fast_sqrt(bdot3(qx, qy, qz, qx, qy, qz));
+  return !(dist > __builtin_fmaf(CULL_LEN_SLACK, __builtin_fmaf(s, norm1(Dx, Dy, Dz), norm1(wx, wy, wz)), reach));
 }
 
 // Segment bundle: every shadow ray of the tile runs from a point within rho of m to the light position
@@ -93,11 +101,11 @@ __device__ __forceinline__ bool ball_may_touch_sweep(float wx, float wy, float w
 __device__ __forceinline__ bool ball_may_touch_segment(float wx, float wy, float wz, float reach, float ex, float ey,
                                                        float ez, float ee)
 {
-  float s = dot3(wx, wy, wz, ex, ey, ez) * fast_rcp(ee); // ee == 0 gives NaN/inf: clamped below, NaN -> pass
+  float s = bdot3(wx, wy, wz, ex, ey, ez) * fast_rcp(ee); // ee == 0 gives NaN/inf: clamped below, NaN -> pass
   s = fminf(fmaxf(s, 0.0f), 1.0f);
-  const float qx = wx - s * ex, qy = wy - s * ey, qz = wz - s * ez;
-  const float dist = fast_sqrt(dot3(qx, qy, qz, qx, qy, qz));
-  return !(dist > reach + CULL_LEN_SLACK * (norm1(wx, wy, wz) + norm1(ex, ey, ez)));
+  const float qx = __builtin_fmaf(-s, ex, wx), qy = __builtin_fmaf(-s, ey, wy), qz = __builtin_fmaf(-s, ez, wz);
+  const float dist = fast_sqrt(bdot3(qx, qy, qz, qx, qy, qz));
+  return !(dist > __builtin_fmaf(CULL_LEN_SLACK, norm1(wx, wy, wz) + norm1(ex, ey, ez), reach));
 }
 
 struct Light {
@@ -125,14 +133,14 @@ __device__ __forceinline__ void bundle_make_slab(Bundle &B, float ax, float ay, 
                                                  bool have)
 {
   float nx = ay * B.Dz - az * B.Dy, ny = az * B.Dx - ax * B.Dz, nz = ax * B.Dy - ay * B.Dx;
-  const float nn = dot3(nx, ny, nz, nx, ny, nz);
+  const float nn = bdot3(nx, ny, nz, nx, ny, nz);
   B.snx = 0.0f; B.sny = 0.0f; B.snz = 0.0f; B.sw = MRT_INF;
   // the angle between axis and direction must be at least ~3 degrees: below that the normal is ill-conditioned
   // (its rounding error is 6e-8 / sin) and the slab is not used
   if (nn > 2.5e-3f * B.DD) {
     const float inv = fast_rsq(nn);
     nx *= inv; ny *= inv; nz *= inv;
-    const float w = wave_max(have ? fabsf(dot3(nx, ny, nz, ex, ey, ez)) : 0.0f);
+    const float w = wave_max(have ? fabsf(bdot3(nx, ny, nz, ex, ey, ez)) : 0.0f);
     B.snx = nx; B.sny = ny; B.snz = nz;
     // a point light's own offset from the plane is pure rounding: |n.(L - m)| <= 1.2e-6 |L - m|
     B.sw = w * CULL_REL + CULL_ABS + (B.point ? 1e-5f * norm1(B.Dx, B.Dy, B.Dz) : 0.0f);
@@ -146,8 +154,8 @@ __device__ __forceinline__ bool bundle_may_touch(const Bundle &B, float cx, floa
   const float wx = cx - B.mx, wy = cy - B.my, wz = cz - B.mz;
   // slab: a shadow ray reaches at most |c - m| + reff along its direction before it can touch the ball, and drifts
   // off the (rounded) plane by at most 1.2e-6 of that
-  if (fabsf(dot3(B.snx, B.sny, B.snz, wx, wy, wz)) > B.sw + reff * CULL_REL + 1e-5f * (norm1(wx, wy, wz) + reff)) return false;
-  const float reach = (reff + B.rho) * CULL_REL + CULL_ABS;
+  if (fabsf(bdot3(B.snx, B.sny, B.snz, wx, wy, wz)) > __builtin_fmaf(1e-5f, norm1(wx, wy, wz) + reff, __builtin_fmaf(reff, CULL_REL, B.sw))) return false;
+  const float reach = __builtin_fmaf(reff + B.rho, CULL_REL, CULL_ABS);
   return B.point ? ball_may_touch_segment(wx, wy, wz, reach, B.Dx, B.Dy, B.Dz, B.DD)
                  : ball_may_touch_sweep(wx, wy, wz, reach, B.Dx, B.Dy, B.Dz, B.DD);
 }
@@ -200,7 +208,7 @@ __device__ __forceinline__ void walk_hierarchy(const float *__restrict__ sclu, i
 // a member sphere's cull radius is sqrt(r^2 + s L^2) <= r + sqrt(s) L
 __device__ __forceinline__ float cluster_cull_radius(float R, float Lmax)
 {
-  return R * CULL_REL + CULL_DISC_SLACK_SQRT * CULL_REL * Lmax + CULL_ABS;
+  return __builtin_fmaf(R, CULL_REL, __builtin_fmaf(CULL_DISC_SLACK_SQRT * CULL_REL, Lmax, CULL_ABS));
 }
 
 } // namespace mrt

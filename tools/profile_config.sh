@@ -1,6 +1,6 @@
 #!/bin/bash
 # rocprofv3 record of one bench config on the GPU box (run through gpurun): a kernel trace with stats, then
-# counter passes, each in a run of its own (MI355X_MICROARCH.md: at most 8 SQ / 4 TCC / 2 GRBM counters per pass,
+# counter passes (two of SQ activity, one of vector instructions by kind, FETCH_SIZE, WRITE_SIZE), each in a run of its own (MI355X_MICROARCH.md: at most 8 SQ / 4 TCC / 2 GRBM counters per pass,
 # FETCH_SIZE and WRITE_SIZE never together, no tracing domains beside --pmc).  The program follows "--" directly.
 # usage: tools/profile_config.sh <round-tag> <config> [bench args...]    e.g. tools/profile_config.sh r02 C3
 # Output: gpurun_out/prof_<tag>_<config>/...; tools/summarize_profile.py turns it into profiles/<tag>_<config>_*.
@@ -22,6 +22,7 @@ pass() { # name counters...
 }
 pass sq1 SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_BUSY_CYCLES
 pass sq2 SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_SCA SQ_INSTS_VALU GRBM_GUI_ACTIVE
+pass sq3 SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_CVT
 pass fetch FETCH_SIZE
 pass write WRITE_SIZE
 echo "[profile] $cfg: done"
