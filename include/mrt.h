@@ -316,6 +316,13 @@ int mrt_render_multi(mrt_ctx *const *ctxs, mrt_comm *const *comms, int32_t n, co
  */
 int mrt_intersect(mrt_ctx *ctx, int prim_kind, const float *prim, const float *rays, float tmin, float tmax,
                   int64_t n, uint8_t *hit, float *t, float *point, float *normal);
+/*
+ * The same with any of rt::Interval's four modes (core/interval.cuh:14-42: each bound closed or open;
+ * mrt_intersect == lower_closed = upper_closed = 1, the mode the reference's tests and its render path use).
+ */
+int mrt_intersect_interval(mrt_ctx *ctx, int prim_kind, const float *prim, const float *rays, float tmin, float tmax,
+                           int lower_closed, int upper_closed, int64_t n, uint8_t *hit, float *t, float *point,
+                           float *normal);
 
 #ifdef __cplusplus
 }

@@ -44,10 +44,16 @@ static inline v3 v3_normalized(v3 a)
 
 typedef struct { v3 o, d; } ray_t;                      /* core/ray.cuh:7-30 */
 typedef struct { float t; v3 point, normal; } hit_t;   /* core/hit_result.cuh:6-10 */
-typedef struct { float lo, hi; } interval_t;           /* core/interval.cuh, closed/closed mode only */
+/* core/interval.cuh:4-48; lo_open / hi_open = 0 is the closed / closed mode the render path uses */
+typedef struct { float lo, hi; int lo_open, hi_open; } interval_t;
 
-/* core/interval.cuh:28-29 */
-static inline int interval_contains(interval_t i, float f) { return (i.lo <= f) && (f <= i.hi); }
+/* core/interval.cuh:25-42: the four modes */
+static inline int interval_contains(interval_t i, float f)
+{
+  const int lo = i.lo_open ? (i.lo < f) : (i.lo <= f);
+  const int hi = i.hi_open ? (f < i.hi) : (f <= i.hi);
+  return lo && hi;
+}
 /* core/ray.cuh:22-25 */
 static inline v3 ray_at(const ray_t *r, float t) { return v3_add(r->o, v3_scale(t, r->d)); }
 
@@ -394,7 +400,7 @@ static int light_color(const orc_scene *s, const hit_t *hit, int hit_index, cons
     st->shadow_rays++;
 
     int obstructed = 0;
-    interval_t I = {1e-3f, plr.hit.t}; /* core/light.cuh:30-31 */
+    interval_t I = {1e-3f, plr.hit.t, 0, 0}; /* core/light.cuh:30-31 */
     for (int oi = 0; oi < s->nobj; ++oi) {
       hit_t other;
       if (object_hit(&s->obj[oi], &plr.ray, I, &other)) { obstructed = 1; break; }
@@ -419,7 +425,7 @@ static v3 color_ray(const orc_scene *s, const ray_t *r, int depth, int max_depth
 {
   if (depth > max_depth) return v3_make(0.01f, 0.01f, 0.01f);
 
-  interval_t I = {0.01f, INFINITY};
+  interval_t I = {0.01f, INFINITY, 0, 0};
   float lowest_t = INFINITY;
   int hit_index = 0, have_hit = 0;
   hit_t best;
@@ -789,7 +795,7 @@ int orc_sphere_hit(const float c[3], float r, const float ro[3], const float rd[
 {
   sphere_t s = {v3_from(c), r};
   ray_t ray = {v3_from(ro), v3_from(rd)};
-  interval_t I = {tmin, tmax};
+  interval_t I = {tmin, tmax, 0, 0};
   hit_t h;
   return emit_hit(sphere_hit(&s, &ray, I, &h), &h, t, point, normal);
 }
@@ -799,9 +805,33 @@ int orc_triangle_hit(const float a[3], const float b[3], const float c[3], const
 {
   triangle_t tr = triangle_make(v3_from(a), v3_from(b), v3_from(c));
   ray_t ray = {v3_from(ro), v3_from(rd)};
-  interval_t I = {tmin, tmax};
+  interval_t I = {tmin, tmax, 0, 0};
   hit_t h;
   return emit_hit(triangle_hit(&tr, &ray, I, &h), &h, t, point, normal);
+}
+
+/* the same with any of the four interval modes (core/interval.cuh:14-23): prim = centre xyz + radius (sphere) or the 16
+ * precomputed floats (triangle) */
+int orc_prim_hit_interval(int geom_kind, const float *prim, const float ro[3], const float rd[3], float tmin, float tmax,
+                          int lower_closed, int upper_closed, float *t, float point[3], float normal[3])
+{
+  ray_t ray = {v3_from(ro), v3_from(rd)};
+  interval_t I = {tmin, tmax, !lower_closed, !upper_closed};
+  hit_t h;
+  if (geom_kind == ORC_GEOM_SPHERE) {
+    sphere_t s = {v3_from(prim), prim[3]};
+    return emit_hit(sphere_hit(&s, &ray, I, &h), &h, t, point, normal);
+  }
+  if (geom_kind == ORC_GEOM_TRIANGLE) {
+    triangle_t tr;
+    memset(&tr, 0, sizeof tr);
+    tr.pn = v3_from(prim + 0); tr.kp = prim[3];
+    tr.ab_c.n = v3_from(prim + 4); tr.ab_c.k = prim[7];
+    tr.bc_a.n = v3_from(prim + 8); tr.bc_a.k = prim[11];
+    tr.ca_b.n = v3_from(prim + 12); tr.ca_b.k = prim[15];
+    return emit_hit(triangle_hit(&tr, &ray, I, &h), &h, t, point, normal);
+  }
+  return emit_hit(0, &h, t, point, normal); /* core/plane.cuh:25-29 */
 }
 
 /* object i as it was added: kind, geometry (sphere: centre xyz, radius; triangle: a, b, c; plane: k, normal), material */
@@ -850,7 +880,7 @@ int orc_triangle16_hit(const float q[16], const float ro[3], const float rd[3], 
   tr.bc_a.n = v3_from(q + 8); tr.bc_a.k = q[11];
   tr.ca_b.n = v3_from(q + 12); tr.ca_b.k = q[15];
   ray_t ray = {v3_from(ro), v3_from(rd)};
-  interval_t I = {tmin, tmax};
+  interval_t I = {tmin, tmax, 0, 0};
   hit_t h;
   return emit_hit(triangle_hit(&tr, &ray, I, &h), &h, t, point, normal);
 }

@@ -90,6 +90,9 @@ int orc_sphere_hit(const float c[3], float r, const float ro[3], const float rd[
                    float *t, float point[3], float normal[3]);
 int orc_triangle_hit(const float a[3], const float b[3], const float c[3], const float ro[3],
                      const float rd[3], float tmin, float tmax, float *t, float point[3], float normal[3]);
+/* ... with any of the four modes of rt::Interval (core/interval.cuh:14-42); prim: 4 floats (sphere) / 16 (triangle) */
+int orc_prim_hit_interval(int geom_kind, const float *prim, const float ro[3], const float rd[3], float tmin, float tmax,
+                          int lower_closed, int upper_closed, float *t, float point[3], float normal[3]);
 int orc_scene_get_object(const orc_scene *s, int i, int *geom_kind, float geom[9], int *mat_kind, float rgb[3]);
 /* Sphere::can_hit (core/sphere.cuh:26-30) and Triangle::can_hit (core/triangle.cuh:68-75); unused by render */
 int orc_sphere_can_hit(const float c[3], float r, const float ro[3], const float rd[3]);

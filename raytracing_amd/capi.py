@@ -22,7 +22,7 @@ PLANE_RGB, PLANE_ID, PLANE_T, PLANES_ALL = 1, 2, 4, 7
 MRT_SYMBOLS = [
     "mrt_device_count", "mrt_ctx_create", "mrt_ctx_destroy", "mrt_ctx_set_option", "mrt_last_error", "mrt_status_string",
     "mrt_triangle_bound", "mrt_rng_state", "mrt_host_alloc", "mrt_host_free", "mrt_scene_upload", "mrt_local_rows", "mrt_render", "mrt_render_device", "mrt_render_device_static", "mrt_scatter_strips",
-    "mrt_scatter_strips_planes", "mrt_gather_strips_planes", "mrt_intersect", "mrt_comm_unique_id", "mrt_comm_create", "mrt_comm_create_local", "mrt_comm_destroy",
+    "mrt_scatter_strips_planes", "mrt_gather_strips_planes", "mrt_intersect", "mrt_intersect_interval", "mrt_comm_unique_id", "mrt_comm_create", "mrt_comm_create_local", "mrt_comm_destroy",
     "mrt_gather_strips", "mrt_render_multi",
 ]
 
@@ -117,6 +117,8 @@ def libmrt():
                                                 C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]
         L.mrt_gather_strips_planes.argtypes = [C.c_void_p] * 7 + [C.c_int32] * 5 + [C.c_void_p]
         L.mrt_intersect.argtypes = [C.c_void_p, C.c_int, _f, _f, C.c_float, C.c_float, C.c_int64, _u8, _f, _f, _f]
+        L.mrt_intersect_interval.argtypes = [C.c_void_p, C.c_int, _f, _f, C.c_float, C.c_float, C.c_int, C.c_int, C.c_int64, _u8,
+                                             _f, _f, _f]
         L.mrt_comm_unique_id.argtypes = [C.c_void_p]
         L.mrt_comm_create.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.POINTER(C.c_void_p)]
         L.mrt_comm_create_local.argtypes = [C.POINTER(C.c_void_p), C.c_int32, C.POINTER(C.c_void_p)]
@@ -499,8 +501,9 @@ class Context:
                                                   v(stream))
         self._check(rc, "mrt_gather_strips")
 
-    def intersect(self, prim_kind, prim, rays, tmin, tmax):
-        """Batched hit test of one primitive against rays [n,6] (origin, direction)."""
+    def intersect(self, prim_kind, prim, rays, tmin, tmax, lower_closed=True, upper_closed=True):
+        """Batched hit test of one primitive against rays [n,6] (origin, direction); the interval's bounds are closed
+        unless said otherwise (rt::Interval's four modes)."""
         prim = np.ascontiguousarray(prim, dtype=np.float32).reshape(-1)
         rays = np.ascontiguousarray(rays, dtype=np.float32).reshape(-1, 6)
         n = rays.shape[0]
@@ -508,8 +511,13 @@ class Context:
         t = np.zeros(n, dtype=np.float32)
         point = np.zeros((n, 3), dtype=np.float32)
         normal = np.zeros((n, 3), dtype=np.float32)
-        rc = self._L.mrt_intersect(self._h, int(prim_kind), _fp(prim), _fp(rays), float(tmin), float(tmax), n,
-                                   hit.ctypes.data_as(_u8), _fp(t), _fp(point), _fp(normal))
+        if lower_closed and upper_closed:
+            rc = self._L.mrt_intersect(self._h, int(prim_kind), _fp(prim), _fp(rays), float(tmin), float(tmax), n,
+                                       hit.ctypes.data_as(_u8), _fp(t), _fp(point), _fp(normal))
+        else:
+            rc = self._L.mrt_intersect_interval(self._h, int(prim_kind), _fp(prim), _fp(rays), float(tmin), float(tmax),
+                                                1 if lower_closed else 0, 1 if upper_closed else 0, n,
+                                                hit.ctypes.data_as(_u8), _fp(t), _fp(point), _fp(normal))
         self._check(rc, "mrt_intersect")
         return hit.astype(bool), t, point, normal
 

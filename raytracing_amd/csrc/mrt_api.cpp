@@ -832,6 +832,14 @@ int mrt_scatter_strips_planes(mrt_ctx *ctx, const void *staging_dev, void *frame
 int mrt_intersect(mrt_ctx *ctx, int prim_kind, const float *prim, const float *rays, float tmin, float tmax, int64_t n,
                   uint8_t *hit, float *t, float *point, float *normal)
 {
+  return mrt_intersect_interval(ctx, prim_kind, prim, rays, tmin, tmax, 1, 1, n, hit, t, point, normal);
+}
+
+int mrt_intersect_interval(mrt_ctx *ctx, int prim_kind, const float *prim, const float *rays, float tmin, float tmax,
+                           int lower_closed, int upper_closed, int64_t n, uint8_t *hit, float *t, float *point,
+                           float *normal)
+{
+  const int mode = (lower_closed ? 0 : 1) | (upper_closed ? 0 : 2);
   if (!ctx || !prim || n < 0 || (n > 0 && (!rays || !hit || !t || !point || !normal))) return MRT_ERR_INVALID;
   if (prim_kind != MRT_GEOM_SPHERE && prim_kind != MRT_GEOM_PLANE && prim_kind != MRT_GEOM_TRIANGLE)
     return fail(ctx, MRT_ERR_INVALID, "unknown primitive kind");
@@ -854,7 +862,7 @@ int mrt_intersect(mrt_ctx *ctx, int prim_kind, const float *prim, const float *r
   do {
     if ((e = hipMemcpyAsync(d_prim, prim, nprim, hipMemcpyHostToDevice, ctx->stream)) != hipSuccess) break;
     if ((e = hipMemcpyAsync(d_rays, rays, b_rays, hipMemcpyHostToDevice, ctx->stream)) != hipSuccess) break;
-    if ((e = mrt::launch_intersect(prim_kind, d_prim, d_rays, tmin, tmax, n, d_hit, d_t, d_point, d_normal,
+    if ((e = mrt::launch_intersect(prim_kind, d_prim, d_rays, tmin, tmax, mode, n, d_hit, d_t, d_point, d_normal,
                                    ctx->stream)) != hipSuccess) break;
     if ((e = hipMemcpyAsync(hit, d_hit, (size_t)n, hipMemcpyDeviceToHost, ctx->stream)) != hipSuccess) break;
     if ((e = hipMemcpyAsync(t, d_t, b_t, hipMemcpyDeviceToHost, ctx->stream)) != hipSuccess) break;

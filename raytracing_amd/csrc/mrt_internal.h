@@ -194,7 +194,8 @@ hipError_t launch_rng_init(const uint32_t *jump_dev, uint32_t *states, uint32_t 
 
 // launchers (mrt_kernels.hip)
 hipError_t launch_render(const RenderArgs &args, hipStream_t stream);
-hipError_t launch_intersect(int prim_kind, const float *prim_dev, const float *rays_dev, float tmin, float tmax,
+// mode: bit 0 the interval's lower bound is open, bit 1 its upper bound (core/interval.cuh:14-23)
+hipError_t launch_intersect(int prim_kind, const float *prim_dev, const float *rays_dev, float tmin, float tmax, int mode,
                             int64_t n, uint8_t *hit_dev, float *t_dev, float *point_dev, float *normal_dev,
                             hipStream_t stream);
 hipError_t launch_stats_reduce(const unsigned long long *slots, int nslots, unsigned long long *out8,

@@ -655,8 +655,29 @@ hipError_t launch_render(const RenderArgs &in, hipStream_t stream)
 // batched single-primitive intersection (the reference's hit_sphere / hit_triangle test kernels)
 // ------------------------------------------------------------------------------------------
 
+// rt::Interval::contains in its four modes (core/interval.cuh:25-42); mode bit 0: lower bound open, bit 1: upper open
+__device__ __forceinline__ bool contains_mode(float lo, float hi, float f, int mode)
+{
+  return ((mode & 1) ? (lo < f) : (lo <= f)) && ((mode & 2) ? (f < hi) : (f <= hi));
+}
+// sphere_roots (mrt_device.h) with the interval's mode
+__device__ __forceinline__ bool sphere_roots_mode(float a, float b, float disc, float lo, float hi, int mode, float &t_out)
+{
+  if (disc > 0.0f) {
+    float sq = sqrtf(disc);
+    float t = (-b - sq) / a;
+    if (contains_mode(lo, hi, t, mode)) { t_out = t; return true; }
+    t = (-b + sq) / a;
+    if (contains_mode(lo, hi, t, mode)) { t_out = t; return true; }
+  } else if (disc == 0.0f) {
+    float t = (-b) / a;
+    if (contains_mode(lo, hi, t, mode)) { t_out = t; return true; }
+  }
+  return false;
+}
+
 __global__ __launch_bounds__(256) void intersect_kernel(int prim_kind, const float *__restrict__ prim,
-                                                        const float *__restrict__ rays, float tmin, float tmax,
+                                                        const float *__restrict__ rays, float tmin, float tmax, int mode,
                                                         int64_t n, uint8_t *hit, float *t_out, float *point,
                                                         float *normal)
 {
@@ -673,7 +694,7 @@ __global__ __launch_bounds__(256) void intersect_kernel(int prim_kind, const flo
     float b = dot3(ocx, ocy, ocz, dx, dy, dz);
     float c = dot3(ocx, ocy, ocz, ocx, ocy, ocz) - r * r;
     float disc = b * b - a * c;
-    ok = sphere_roots(a, b, disc, tmin, tmax, t);
+    ok = sphere_roots_mode(a, b, disc, tmin, tmax, mode, t);
     if (ok) {
       px = ox + t * dx; py = oy + t * dy; pz = oz + t * dz;
       nx = px - cx; ny = py - cy; nz = pz - cz;
@@ -687,7 +708,7 @@ __global__ __launch_bounds__(256) void intersect_kernel(int prim_kind, const flo
       bool inside = (dot3(prim[4], prim[5], prim[6], qx, qy, qz) - prim[7]) > -1e-6f &&
                     (dot3(prim[8], prim[9], prim[10], qx, qy, qz) - prim[11]) > -1e-6f &&
                     (dot3(prim[12], prim[13], prim[14], qx, qy, qz) - prim[15]) > -1e-6f;
-      if (inside && contains(tmin, tmax, tt)) {
+      if (inside && contains_mode(tmin, tmax, tt, mode)) {
         ok = true; t = tt; px = qx; py = qy; pz = qz;
         const bool front = rdn < 0;
         nx = front ? prim[0] : -prim[0]; ny = front ? prim[1] : -prim[1]; nz = front ? prim[2] : -prim[2];
@@ -700,14 +721,14 @@ __global__ __launch_bounds__(256) void intersect_kernel(int prim_kind, const flo
   normal[3 * i] = nx; normal[3 * i + 1] = ny; normal[3 * i + 2] = nz;
 }
 
-hipError_t launch_intersect(int prim_kind, const float *prim_dev, const float *rays_dev, float tmin, float tmax,
+hipError_t launch_intersect(int prim_kind, const float *prim_dev, const float *rays_dev, float tmin, float tmax, int mode,
                             int64_t n, uint8_t *hit_dev, float *t_dev, float *point_dev, float *normal_dev,
                             hipStream_t stream)
 {
   if (n <= 0) return hipSuccess;
   const unsigned blocks = unsigned((n + 255) / 256);
   hipLaunchKernelGGL(intersect_kernel, dim3(blocks), dim3(256), 0, stream, prim_kind, prim_dev, rays_dev, tmin, tmax,
-                     n, hit_dev, t_dev, point_dev, normal_dev);
+                     mode, n, hit_dev, t_dev, point_dev, normal_dev);
   return hipGetLastError();
 }
 

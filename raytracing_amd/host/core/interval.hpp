@@ -17,8 +17,9 @@ public:
   }
   float lower() const { return lower_; }
   float upper() const { return upper_; }
-  // the GPU path implements the closed/closed mode only (the only one the render path uses,
-  // src/main.cu:60 and core/light.cuh:31)
+  // (the render path only ever uses the closed/closed mode, src/main.cu:60 and core/light.cuh:31; rt::hit() takes all four)
+  bool lower_closed() const { return lower_closed_; }
+  bool upper_closed() const { return upper_closed_; }
   bool is_closed() const { return lower_closed_ && upper_closed_; }
 
 private:

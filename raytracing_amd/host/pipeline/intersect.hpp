@@ -21,14 +21,14 @@ namespace internal {
 inline std::vector<std::optional<HitResult>> intersect(mrt_ctx *ctx, int kind, const float *prim,
                                                        const std::vector<Ray> &rays, const Interval &I)
 {
-  if (!I.is_closed()) checkRtErrors(MRT_ERR_INVALID); // only the closed/closed mode exists on the GPU
   const std::size_t n = rays.size();
   std::vector<float> r(6 * n), t(n), point(3 * n), normal(3 * n);
   std::vector<std::uint8_t> hit(n);
   for (std::size_t i = 0; i < n; ++i)
     for (int k = 0; k < 3; ++k) { r[6 * i + k] = rays[i].origin()[k]; r[6 * i + 3 + k] = rays[i].direction()[k]; }
-  checkRtErrors(mrt_intersect(ctx, kind, prim, r.data(), I.lower(), I.upper(), static_cast<std::int64_t>(n), hit.data(),
-                              t.data(), point.data(), normal.data()));
+  checkRtErrors(mrt_intersect_interval(ctx, kind, prim, r.data(), I.lower(), I.upper(), I.lower_closed() ? 1 : 0,
+                                       I.upper_closed() ? 1 : 0, static_cast<std::int64_t>(n), hit.data(), t.data(),
+                                       point.data(), normal.data()));
   std::vector<std::optional<HitResult>> out(n);
   for (std::size_t i = 0; i < n; ++i)
     if (hit[i])

@@ -81,6 +81,13 @@ static void test_triangle(rt::Renderer &gpu)
                       rt::Interval(0.01f, 100.0f));
   EXPECT_TRUE(!hits[0].has_value());
   EXPECT_TRUE(!hits[1].has_value());
+  std::printf("[ RUN      ] TestTriangle.IntervalModes\n"); // core/interval.cuh:14-42: t = 1 is a bound of the interval
+  const rt::Ray down(Vec3f{0, 0, 0}, Vec3f{0, 0, -1});
+  EXPECT_TRUE(rt::hit(gpu.ctx(), t, {down}, rt::Interval(1.0f, 100.0f))[0].has_value());
+  EXPECT_TRUE(!rt::hit(gpu.ctx(), t, {down}, rt::Interval(1.0f, 100.0f, false, true))[0].has_value());
+  EXPECT_TRUE(rt::hit(gpu.ctx(), t, {down}, rt::Interval(-1.0f, 1.0f))[0].has_value());
+  EXPECT_TRUE(!rt::hit(gpu.ctx(), t, {down}, rt::Interval(-1.0f, 1.0f, true, false))[0].has_value());
+  EXPECT_TRUE(rt::hit(gpu.ctx(), t, {down}, rt::Interval(-1.0f, 100.0f, false, false))[0].has_value());
 }
 
 static void test_default_scene_frame(rt::Renderer &gpu)

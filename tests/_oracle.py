@@ -236,6 +236,17 @@ def triangle16_hit(q, ro, rd, tmin, tmax):
     return (bool(ok), np.float32(t.value), np.array(p[:], np.float32), np.array(n[:], np.float32))
 
 
+def prim_hit_interval(geom_kind, prim, ro, rd, tmin, tmax, lower_closed=True, upper_closed=True):
+    """One primitive (4 floats: sphere; 16: precomputed triangle) under any of rt::Interval's four modes."""
+    t, p, n = _hit_out()
+    arr = np.ascontiguousarray(prim, np.float32)
+    f = lib().orc_prim_hit_interval
+    f.argtypes = [C.c_int, C.POINTER(C.c_float), _f3, _f3, C.c_float, C.c_float, C.c_int, C.c_int, C.POINTER(C.c_float), _f3, _f3]
+    ok = f(int(geom_kind), arr.ctypes.data_as(C.POINTER(C.c_float)), _v(ro), _v(rd), float(tmin), float(tmax),
+           1 if lower_closed else 0, 1 if upper_closed else 0, C.byref(t), p, n)
+    return (bool(ok), np.float32(t.value), np.array(p[:], np.float32), np.array(n[:], np.float32))
+
+
 def sphere_can_hit(c, r, ro, rd):
     return bool(lib().orc_sphere_can_hit(_v(c), float(r), _v(ro), _v(rd)))
 

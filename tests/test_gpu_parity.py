@@ -82,6 +82,41 @@ def test_triangle_known_answers(gpu_ctx, case):
     assert t[0] == ot and np.array_equal(p[0], op) and np.array_equal(n[0], on)
 
 
+@pytest.mark.parametrize("lower_closed,upper_closed", [(True, True), (True, False), (False, True), (False, False)])
+def test_interval_modes_of_the_hit_tests(gpu_ctx, kernel_mode, lower_closed, upper_closed):
+    """rt::Interval's four modes (core/interval.cuh:14-42) through mrt_intersect_interval: rays whose hit parameter
+    IS a bound of the interval (the reference's known-answer geometry: t = 1 on the sphere, t = 3 on the triangle), which
+    the modes tell apart, and 2 000 random rays whose intervals end on hits of their own; GPU = oracle, bit for bit."""
+    if kernel_mode != "cull":
+        pytest.skip("the hit tests do not depend on the render kernel")
+    sph = [0.0, 0.0, -2.0, 1.0]                       # test/spheretest.cu:16: t = 1
+    tri16 = capi.triangle_precompute(np.float32([[[0, -1, -3], [1, 1, -4], [-1, 1, -2]]]))[:, 0]   # triangletest.cu:72: t = 3
+    cases = [(capi.GEOM_SPHERE, sph, [0, 0, 0, 0, 0, -1], 1.0), (capi.GEOM_TRIANGLE, tri16, [0, 0.5, 0, 0, 0, -1], 3.0)]
+    for kind, prim, ray, t_hit in cases:
+        for lo, hi in ((t_hit, 100.0), (-1.0, t_hit), (t_hit, t_hit), (-1.0, 100.0)):
+            hit, t, p, n = gpu_ctx.intersect(kind, prim, np.float32([ray]), lo, hi, lower_closed, upper_closed)
+            ok, ot, op, on = O.prim_hit_interval(kind, prim, ray[:3], ray[3:], lo, hi, lower_closed, upper_closed)
+            assert bool(hit[0]) == ok, (kind, lo, hi, lower_closed, upper_closed)
+            if kind == capi.GEOM_TRIANGLE:   # one root: the modes decide (a sphere goes on to its far root, t = 3)
+                expect = (lo < t_hit or (lower_closed and lo == t_hit)) and (t_hit < hi or (upper_closed and hi == t_hit))
+                assert ok == expect, (lo, hi, lower_closed, upper_closed)
+            if ok:
+                assert t[0] == ot and np.array_equal(p[0], op) and np.array_equal(n[0], on)
+    # random rays: first the closed test over a wide interval, then intervals that end exactly on the t found
+    rays = _random_rays(8000, 77)
+    for kind, prim in ((capi.GEOM_SPHERE, sph), (capi.GEOM_TRIANGLE, tri16)):
+        h0, t0, _, _ = gpu_ctx.intersect(kind, prim, rays, -50.0, 50.0)
+        assert h0.sum() > 50
+        for which in ("lower", "upper"):
+            for i in np.flatnonzero(h0)[:150]:
+                lo, hi = (float(t0[i]), 50.0) if which == "lower" else (-50.0, float(t0[i]))
+                hit, t, p, n = gpu_ctx.intersect(kind, prim, rays[i:i + 1], lo, hi, lower_closed, upper_closed)
+                ok, ot, op, on = O.prim_hit_interval(kind, prim, rays[i, :3], rays[i, 3:], lo, hi, lower_closed, upper_closed)
+                assert bool(hit[0]) == ok
+                if ok:
+                    assert t[0] == ot and np.array_equal(p[0], op) and np.array_equal(n[0], on)
+
+
 def _random_rays(n, seed):
     rng = np.random.default_rng(seed)
     o = rng.uniform(-3, 3, (n, 3)).astype(np.float32)

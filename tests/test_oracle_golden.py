@@ -120,3 +120,25 @@ def test_multisample_mode_runs_and_averages():
     # the top rows are sky for every sub-sample: jitter barely changes the gradient there
     assert (one["id"][-4:] == -1).all()
     assert np.abs(one["rgb"][-4:] - many["rgb"][-4:]).max() < 5e-3
+
+
+def test_interval_modes():
+    """core/interval.cuh:14-42: a root that IS a bound of the interval counts under a closed bound only (the reference's
+    sphere known answer: roots t = 1 and t = 3; and a triangle, which has one)."""
+    from raytracing_amd import capi
+    sph, ro, rd = [0.0, 0.0, -2.0, 1.0], [0.0, 0.0, 0.0], [0.0, 0.0, -1.0]
+    for lc in (True, False):
+        for uc in (True, False):
+            # (an open lower bound at the near root: Sphere::hit goes on to the far root, core/sphere.cuh:52-58)
+            ok, t, _, _ = O.prim_hit_interval(capi.GEOM_SPHERE, sph, ro, rd, 1.0, 100.0, lc, uc)
+            assert ok and t == (1.0 if lc else 3.0)
+            assert O.prim_hit_interval(capi.GEOM_SPHERE, sph, ro, rd, -1.0, 1.0, lc, uc)[0] == uc
+            assert O.prim_hit_interval(capi.GEOM_SPHERE, sph, ro, rd, -1.0, 100.0, lc, uc)[0]
+            assert O.prim_hit_interval(capi.GEOM_SPHERE, sph, ro, rd, 1.0, 1.0, lc, uc)[0] == (lc and uc)
+    ok, t, p, n = O.prim_hit_interval(capi.GEOM_SPHERE, sph, ro, rd, -1.0, 100.0)
+    assert O.sphere_hit(sph[:3], sph[3], ro, rd, -1.0, 100.0)[1] == t == 1.0
+    tri16 = capi.triangle_precompute(np.float32([[[0, -1, -3], [1, 1, -4], [-1, 1, -2]]]))[:, 0]   # test/triangletest.cu:72: t = 3
+    for lc in (True, False):
+        for uc in (True, False):
+            assert O.prim_hit_interval(capi.GEOM_TRIANGLE, tri16, [0, 0.5, 0], [0, 0, -1], 3.0, 100.0, lc, uc)[0] == lc
+            assert O.prim_hit_interval(capi.GEOM_TRIANGLE, tri16, [0, 0.5, 0], [0, 0, -1], -1.0, 3.0, lc, uc)[0] == uc
