@@ -1317,6 +1317,9 @@ __device__ __forceinline__ void bin_ball(const RenderArgs &A, int g, float &wx, 
 __device__ __forceinline__ void bin_try_tile(const RenderArgs &A, int TW, int tiles_x, int g, float wx, float wy, float wz, float reff,
                                              int tx, int ty, uint32_t *__restrict__ cnt, uint32_t *__restrict__ list)
 {
+  // a rank of a partitioned frame only lists the tiles of its own strips (strips are multiples of 8 rows: a tile row
+  // belongs to one strip)
+  if (A.nranks > 1 && ((ty * 8) / A.strip_rows) % A.nranks != A.rank) return;
   const TileCone t = make_tile_cone(A.cam, A.W, A.H, A.cone_ext, tx, TW, ty * 8);
   if (!ball_may_touch_cone(wx, wy, wz, reff, t.cax, t.cay, t.caz, t.cosT, t.sinT)) return;
   const int n0 = bin_items0(A);
