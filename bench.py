@@ -331,8 +331,37 @@ def measure(env, name, headline):
     warmup = args.warmup if args.warmup is not None else 5
     planes = {"all": capi.PLANES_ALL, "rgb": capi.PLANE_RGB}[args.planes]
 
+    # N > 1: how many shares of the frame rank 0 takes (multigpu.suggest_root_share).  "auto": rank 0 times the whole
+    # frame on its GPU alone and the ranks agree on the share that balances its render against what it has to receive.
+    root_share, share_how = 1, None
+    if world > 1:
+        k = torch.zeros(1, dtype=torch.int64, device=torch.device(f"cuda:{env.local_rank}"))
+        if args.root_share != "auto":
+            k[0] = max(1, int(args.root_share))
+            share_how = "--root-share"
+        elif rank == 0:
+            probe = multigpu.FrameRenderer(flat, cam12, W, H, device=env.local_rank, spp=spp, max_depth=max_depth)
+            probe.ctx.set_cull(0 if args.brute_force else 1)
+            for _ in range(5):
+                probe.render_local()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            torch.cuda.synchronize()
+            e0.record()
+            for _ in range(10):
+                probe.render_local()
+            e1.record()
+            torch.cuda.synchronize()
+            one_gpu_ms = e0.elapsed_time(e1) / 10
+            probe.close()
+            k[0] = multigpu.suggest_root_share(one_gpu_ms, W * H * 4 * multigpu.plane_dwords(planes), world,
+                                               link_gbps=args.link_gbps)
+        dist.broadcast(k, 0)
+        root_share = int(k.item())
+        if share_how is None:
+            share_how = (f"auto: the whole frame on one GPU against the bytes rank 0 receives at {args.link_gbps} GB/s per "
+                         "link (multigpu.suggest_root_share)")
     fr = multigpu.FrameRenderer(flat, cam12, W, H, rank=rank, num_ranks=world, device=env.local_rank, spp=spp,
-                                max_depth=max_depth, planes=planes, pipeline=args.pipeline)
+                                max_depth=max_depth, planes=planes, pipeline=args.pipeline, root_share=root_share)
     fr.ctx.set_cull(0 if args.brute_force else 1)
     gather = make_comm(env, fr)
     bytes_pp = BYTES_PER_PIXEL
@@ -510,7 +539,7 @@ def measure(env, name, headline):
                          "binding_resource": "vector-instruction issue, not HBM (see executed_work.valu_issue_measured_costs; DESIGN.md 5.5)"},
         }
         if world > 1:
-            out["multi_gpu"] = {**multi, "exchange_overlaps_next_render": multi["pipeline_depth"] > 1,
+            out["multi_gpu"] = {**multi, "root_share_how": share_how, "exchange_overlaps_next_render": multi["pipeline_depth"] > 1,
                                 "carrier": gather}
         if pmc and "SQ_INSTS_VALU" in pmc:
             # what the kernel executed, not what a brute-force kernel would have: committed counter passes
@@ -594,6 +623,10 @@ def main():
                     help="N > 1: what the ranks render for and send to rank 0 (rgb: the picture alone, 12 of 20 B/pixel)")
     ap.add_argument("--pipeline", type=int, default=2, choices=(1, 2),
                     help="N > 1: frames in flight (2: the exchange of a frame overlaps the next frame's render)")
+    ap.add_argument("--root-share", default="auto",
+                    help="N > 1: shares of the frame rank 0 renders of N - 1 + that many (1: every rank the same; auto: "
+                         "balanced against the exchange)")
+    ap.add_argument("--link-gbps", type=float, default=45.0, help="achievable GB/s of one xGMI link, for --root-share auto")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--brute-force", action="store_true", help="use the every-ray-every-primitive kernel")
     ap.add_argument("--dump-frame", default=None, help="rank 0 saves the headline's last frame (rgb, id, t) to this .npz")

@@ -95,7 +95,7 @@ typedef struct mrt_camera {
  * Strip partition of a frame over ranks (no reference counterpart: the reference is
  * single GPU).  Rows are dealt in strips of strip_rows rows,
  * strip s -> rank s % num_ranks.  A rank's local buffer holds its strips back to
- * back in ascending order (frame_layout 0).  {0,1,8,0} renders the whole frame.
+ * back in ascending order (frame_layout 0).  {0,1,8,0,0} renders the whole frame.
  */
 typedef struct mrt_partition {
   int32_t rank;
@@ -104,6 +104,10 @@ typedef struct mrt_partition {
   int32_t frame_layout; /* 0: the buffers hold the rank's rows back to back (local_rows x W);
                            1: the buffers are whole H x W frames and the rank writes only its own rows, each at its
                               final place (rank 0 of a multi-GPU frame renders like this and receives the rest) */
+  int32_t rank_span;    /* 0 or 1: the strips of `rank` alone.  k > 1: the strips of ranks rank .. rank + k - 1 in ONE
+                           render (in ascending strip order) -- how rank 0 of a WEIGHTED multi-GPU frame takes several
+                           shares of a partition into more shares than GPUs (mrt_gather_strips_root).  At most 65535
+                           ranks; rank + k <= num_ranks */
 } mrt_partition;
 
 typedef struct mrt_render_params {
@@ -250,6 +254,12 @@ int mrt_scatter_strips_planes(mrt_ctx *ctx, const void *staging_dev, void *frame
                               void *frame_t_dev, int32_t width, int32_t height, int32_t num_ranks, int32_t strip_rows,
                               int32_t skip_rank, int32_t planes, void *stream);
 
+/* ... when the ranks skip_rank .. skip_rank + skip_span - 1 were rendered in place (one context that took several
+ * shares of the partition: mrt_partition.rank_span); mrt_scatter_strips_planes == skip_span 1 */
+int mrt_scatter_strips_span(mrt_ctx *ctx, const void *staging_dev, void *frame_rgb_dev, void *frame_id_dev,
+                            void *frame_t_dev, int32_t width, int32_t height, int32_t num_ranks, int32_t strip_rows,
+                            int32_t skip_rank, int32_t skip_span, int32_t planes, void *stream);
+
 /*
  * --- multi-GPU frames over RCCL, behind the C-ABI (no reference counterpart: the reference is single GPU and has
  * no collective call).  The library opens RCCL (librccl.so.1) at the first mrt_comm_* call; a process
@@ -294,6 +304,19 @@ int mrt_gather_strips(mrt_ctx *ctx, mrt_comm *comm, const void *packed_dev, void
 int mrt_gather_strips_planes(mrt_ctx *ctx, mrt_comm *comm, const void *packed_dev, void *staging_dev,
                              void *frame_rgb_dev, void *frame_id_dev, void *frame_t_dev, int32_t width, int32_t height,
                              int32_t strip_rows, int32_t root_in_place, int32_t planes, void *stream);
+/*
+ * The WEIGHTED exchange (no reference counterpart): rank 0 renders more than 1 / N of the frame.  Where the exchange
+ * bounds a multi-GPU frame -- rank 0 receives (N - 1) / N of it over its links while a GPU renders all of it in less
+ * time -- the frame is dealt in V = N - 1 + root_span shares (strip s -> share s % V); rank 0 renders shares
+ * 0 .. root_span - 1 in one call, in place (mrt_partition {0, V, strip_rows, 1, root_span}), rank r >= 1 renders share
+ * root_span + r - 1 ({root_span + r - 1, V, strip_rows, 0, 0}) into its packed buffer, and every rank calls this with
+ * the same root_span: the peers send, rank 0 receives into staging_dev (rank order) and scatters.  root_span 1 ==
+ * mrt_gather_strips_planes with root_in_place.  At most 64 shares.  The frame is bit-identical to the one-GPU frame
+ * whatever the shares.
+ */
+int mrt_gather_strips_root(mrt_ctx *ctx, mrt_comm *comm, const void *packed_dev, void *staging_dev, void *frame_rgb_dev,
+                           void *frame_id_dev, void *frame_t_dev, int32_t width, int32_t height, int32_t strip_rows,
+                           int32_t root_span, int32_t planes, void *stream);
 
 /*
  * One process, n GPUs, blocking, HOST buffers: the multi-GPU form of mrt_render.  ctxs[i] renders the strips of rank

@@ -22,7 +22,7 @@ PLANE_RGB, PLANE_ID, PLANE_T, PLANES_ALL = 1, 2, 4, 7
 MRT_SYMBOLS = [
     "mrt_device_count", "mrt_ctx_create", "mrt_ctx_destroy", "mrt_ctx_set_option", "mrt_last_error", "mrt_status_string",
     "mrt_triangle_bound", "mrt_rng_state", "mrt_host_alloc", "mrt_host_free", "mrt_scene_upload", "mrt_local_rows", "mrt_render", "mrt_render_device", "mrt_render_device_static", "mrt_scatter_strips",
-    "mrt_scatter_strips_planes", "mrt_gather_strips_planes", "mrt_intersect", "mrt_intersect_interval", "mrt_comm_unique_id", "mrt_comm_create", "mrt_comm_create_local", "mrt_comm_destroy",
+    "mrt_scatter_strips_planes", "mrt_scatter_strips_span", "mrt_gather_strips_planes", "mrt_gather_strips_root", "mrt_intersect", "mrt_intersect_interval", "mrt_comm_unique_id", "mrt_comm_create", "mrt_comm_create_local", "mrt_comm_destroy",
     "mrt_gather_strips", "mrt_render_multi",
 ]
 
@@ -61,7 +61,8 @@ class Camera(C.Structure):
 
 
 class Partition(C.Structure):
-    _fields_ = [("rank", C.c_int32), ("num_ranks", C.c_int32), ("strip_rows", C.c_int32), ("frame_layout", C.c_int32)]
+    _fields_ = [("rank", C.c_int32), ("num_ranks", C.c_int32), ("strip_rows", C.c_int32), ("frame_layout", C.c_int32),
+                ("rank_span", C.c_int32)]
 
 
 class RenderParams(C.Structure):
@@ -116,6 +117,8 @@ def libmrt():
         L.mrt_scatter_strips_planes.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,
                                                 C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]
         L.mrt_gather_strips_planes.argtypes = [C.c_void_p] * 7 + [C.c_int32] * 5 + [C.c_void_p]
+        L.mrt_scatter_strips_span.argtypes = [C.c_void_p] * 5 + [C.c_int32] * 7 + [C.c_void_p]
+        L.mrt_gather_strips_root.argtypes = [C.c_void_p] * 7 + [C.c_int32] * 5 + [C.c_void_p]
         L.mrt_intersect.argtypes = [C.c_void_p, C.c_int, _f, _f, C.c_float, C.c_float, C.c_int64, _u8, _f, _f, _f]
         L.mrt_intersect_interval.argtypes = [C.c_void_p, C.c_int, _f, _f, C.c_float, C.c_float, C.c_int, C.c_int, C.c_int64, _u8,
                                              _f, _f, _f]
@@ -338,8 +341,8 @@ def device_count():
     return n.value
 
 
-def local_rows(height, rank=0, num_ranks=1, strip_rows=8):
-    p = Partition(rank, num_ranks, strip_rows)
+def local_rows(height, rank=0, num_ranks=1, strip_rows=8, rank_span=1):
+    p = Partition(rank, num_ranks, strip_rows, 0, rank_span)
     r = C.c_int32(0)
     rc = libmrt().mrt_local_rows(height, C.byref(p), C.byref(r))
     if rc != 0:
@@ -347,12 +350,14 @@ def local_rows(height, rank=0, num_ranks=1, strip_rows=8):
     return r.value
 
 
-def local_row_index(height, rank, num_ranks, strip_rows=8):
-    """Global row numbers of a rank's local rows, in local order (host mirror of the strip rule)."""
+def local_row_index(height, rank, num_ranks, strip_rows=8, rank_span=1):
+    """Global row numbers of a rank's local rows, in local order (host mirror of the strip rule); rank_span > 1: the
+    strips of ranks rank .. rank + rank_span - 1 (mrt_partition.rank_span)."""
     rows = []
     nstrips = (height + strip_rows - 1) // strip_rows
-    for s in range(rank, nstrips, num_ranks):
-        rows.extend(range(s * strip_rows, min(height, (s + 1) * strip_rows)))
+    for s in range(nstrips):
+        if rank <= s % num_ranks < rank + max(1, rank_span):
+            rows.extend(range(s * strip_rows, min(height, (s + 1) * strip_rows)))
     return np.asarray(rows, dtype=np.int64)
 
 
@@ -427,20 +432,20 @@ class Context:
         self._check(self._L.mrt_scene_upload(self._h, C.byref(d)), "mrt_scene_upload")
 
     @staticmethod
-    def _params(W, H, spp, max_depth, rank, num_ranks, strip_rows, frame_layout=0):
+    def _params(W, H, spp, max_depth, rank, num_ranks, strip_rows, frame_layout=0, rank_span=1):
         p = RenderParams()
         p.width, p.height, p.spp, p.max_depth = W, H, spp, max_depth
-        p.part = Partition(rank, num_ranks, strip_rows, frame_layout)
+        p.part = Partition(rank, num_ranks, strip_rows, frame_layout, rank_span)
         return p
 
-    def render(self, cam12, W, H, spp=1, max_depth=0, rank=0, num_ranks=1, strip_rows=8, want_stats=True):
+    def render(self, cam12, W, H, spp=1, max_depth=0, rank=0, num_ranks=1, strip_rows=8, want_stats=True, rank_span=1):
         """Blocking render into host arrays of the rank's local rows."""
-        rows = local_rows(H, rank, num_ranks, strip_rows)
+        rows = local_rows(H, rank, num_ranks, strip_rows, rank_span)
         rgb = np.zeros((rows, W, 3), dtype=np.float32)
         ids = np.full((rows, W), -2, dtype=np.int32)
         t = np.zeros((rows, W), dtype=np.float32)
         cam = Camera.from12(cam12)
-        p = self._params(W, H, spp, max_depth, rank, num_ranks, strip_rows)
+        p = self._params(W, H, spp, max_depth, rank, num_ranks, strip_rows, 0, rank_span)
         st = Stats()
         rc = self._L.mrt_render(self._h, C.byref(cam), C.byref(p), rgb.ctypes.data, ids.ctypes.data, t.ctypes.data,
                                 C.byref(st) if want_stats else None)
@@ -461,12 +466,12 @@ class Context:
         return st.as_dict()
 
     def render_device(self, cam12, W, H, rgb_ptr, id_ptr=None, t_ptr=None, stats_ptr=None, stream=None, spp=1,
-                      max_depth=0, rank=0, num_ranks=1, strip_rows=8, frame_layout=0, static=False):
+                      max_depth=0, rank=0, num_ranks=1, strip_rows=8, frame_layout=0, static=False, rank_span=1):
         """Asynchronous render into device buffers (raw pointers, e.g. torch tensor.data_ptr()): the rank's rows
         back to back, or (frame_layout=1) at their final places in whole-frame buffers.  static=True goes through
         mrt_render_device_static, the entry point that allocates nothing."""
         cam = Camera.from12(cam12)
-        p = self._params(W, H, spp, max_depth, rank, num_ranks, strip_rows, frame_layout)
+        p = self._params(W, H, spp, max_depth, rank, num_ranks, strip_rows, frame_layout, rank_span)
         fn = self._L.mrt_render_device_static if static else self._L.mrt_render_device
         rc = fn(self._h, C.byref(cam), C.byref(p), C.c_void_p(rgb_ptr), C.c_void_p(id_ptr) if id_ptr else None,
                 C.c_void_p(t_ptr) if t_ptr else None, C.c_void_p(stats_ptr) if stats_ptr else None,
@@ -474,12 +479,16 @@ class Context:
         self._check(rc, "mrt_render_device_static" if static else "mrt_render_device")
 
     def scatter_strips(self, staging_ptr, rgb_ptr, id_ptr, t_ptr, W, H, num_ranks, strip_rows=8, skip_rank=0,
-                       stream=None, planes=None):
+                       stream=None, planes=None, skip_span=1):
         """Rank 0 after the gather: the packed buffers of the ranks other than skip_rank (in rank order at
         staging_ptr) go to their strips' places in the three frame planes.  planes: PLANE_* mask of what the packed
         buffers hold (None: all three, through the older entry point)."""
         v = lambda p: C.c_void_p(p) if p else None
-        if planes is None:
+        if skip_span != 1:   # (the ranks skip_rank .. skip_rank + skip_span - 1 were rendered in place)
+            rc = self._L.mrt_scatter_strips_span(self._h, v(staging_ptr), v(rgb_ptr), v(id_ptr), v(t_ptr), W, H, num_ranks,
+                                                 strip_rows, skip_rank, skip_span, int(PLANES_ALL if planes is None else planes),
+                                                 v(stream))
+        elif planes is None:
             rc = self._L.mrt_scatter_strips(self._h, v(staging_ptr), v(rgb_ptr), v(id_ptr), v(t_ptr), W, H, num_ranks,
                                             strip_rows, skip_rank, v(stream))
         else:
@@ -488,11 +497,15 @@ class Context:
         self._check(rc, "mrt_scatter_strips")
 
     def gather_strips(self, comm, packed_ptr, staging_ptr, rgb_ptr, id_ptr, t_ptr, W, H, strip_rows=8, root_in_place=True,
-                      stream=None, planes=None):
+                      stream=None, planes=None, root_span=1):
         """The exchange step of a multi-GPU frame over RCCL (mrt_gather_strips): ranks other than 0 send their packed
         buffer, rank 0 receives them all and puts the strips in place.  Asynchronous on `stream`."""
         v = lambda p: C.c_void_p(p) if p else None
-        if planes is None:
+        if root_span != 1:   # the weighted exchange: rank 0 rendered root_span shares of ranks - 1 + root_span in place
+            rc = self._L.mrt_gather_strips_root(self._h, comm._h, v(packed_ptr), v(staging_ptr), v(rgb_ptr), v(id_ptr),
+                                                v(t_ptr), W, H, strip_rows, int(root_span),
+                                                int(PLANES_ALL if planes is None else planes), v(stream))
+        elif planes is None:
             rc = self._L.mrt_gather_strips(self._h, comm._h, v(packed_ptr), v(staging_ptr), v(rgb_ptr), v(id_ptr),
                                            v(t_ptr), W, H, strip_rows, 1 if root_in_place else 0, v(stream))
         else:

@@ -626,17 +626,21 @@ int mrt_scene_upload(mrt_ctx *ctx, const mrt_scene_desc *s)
   return MRT_OK;
 }
 
+static int span_of(const mrt_partition &p) { return p.rank_span > 1 ? p.rank_span : 1; }
+
 static bool partition_ok(const mrt_partition &p)
 {
-  return p.num_ranks >= 1 && p.rank >= 0 && p.rank < p.num_ranks && p.strip_rows >= 8 && (p.strip_rows % 8) == 0 &&
-         (p.frame_layout == 0 || p.frame_layout == 1);
+  return p.num_ranks >= 1 && p.num_ranks <= 0xffff && p.rank >= 0 && p.rank_span >= 0 && p.rank + span_of(p) <= p.num_ranks &&
+         p.strip_rows >= 8 && (p.strip_rows % 8) == 0 && (p.frame_layout == 0 || p.frame_layout == 1);
 }
 
 static int local_rows_of(int H, const mrt_partition &p)
 {
-  const int nstrips = (H + p.strip_rows - 1) / p.strip_rows;
+  const int nstrips = (H + p.strip_rows - 1) / p.strip_rows, span = span_of(p);
   int rows = 0;
-  for (int s = p.rank; s < nstrips; s += p.num_ranks) {
+  for (int s = 0; s < nstrips; ++s) {
+    const int r = s % p.num_ranks;
+    if (r < p.rank || r >= p.rank + span) continue;
     const int r0 = s * p.strip_rows;
     rows += (r0 + p.strip_rows <= H) ? p.strip_rows : (H - r0);
   }
@@ -668,7 +672,7 @@ static int fill_args(mrt_ctx *ctx, const mrt_camera *cam, const mrt_render_param
   A.cam.vx = cam->vertical[0]; A.cam.vy = cam->vertical[1]; A.cam.vz = cam->vertical[2];
   A.cam.ux = cam->up_left[0]; A.cam.uy = cam->up_left[1]; A.cam.uz = cam->up_left[2];
   A.W = p->width; A.H = p->height;
-  A.rank = p->part.rank; A.nranks = p->part.num_ranks; A.strip_rows = p->part.strip_rows;
+  A.rank = mrt::pack_rank(p->part.rank, span_of(p->part)); A.nranks = p->part.num_ranks; A.strip_rows = p->part.strip_rows;
   A.local_rows = local_rows_of(p->height, p->part);
   A.frame_layout = p->part.frame_layout;
   A.spp = p->spp;
@@ -803,7 +807,17 @@ int mrt_scatter_strips_planes(mrt_ctx *ctx, const void *staging_dev, void *frame
                               void *frame_t_dev, int32_t width, int32_t height, int32_t num_ranks, int32_t strip_rows,
                               int32_t skip_rank, int32_t planes, void *stream)
 {
+  return mrt_scatter_strips_span(ctx, staging_dev, frame_rgb_dev, frame_id_dev, frame_t_dev, width, height, num_ranks,
+                                 strip_rows, skip_rank, 1, planes, stream);
+}
+
+int mrt_scatter_strips_span(mrt_ctx *ctx, const void *staging_dev, void *frame_rgb_dev, void *frame_id_dev,
+                            void *frame_t_dev, int32_t width, int32_t height, int32_t num_ranks, int32_t strip_rows,
+                            int32_t skip_rank, int32_t skip_span, int32_t planes, void *stream)
+{
   if (!ctx) return MRT_ERR_INVALID;
+  if (skip_span < 1 || (skip_rank >= 0 && skip_rank + skip_span > num_ranks))
+    return fail(ctx, MRT_ERR_INVALID, "skip_span out of range");
   if (!planes_ok(planes)) return fail(ctx, MRT_ERR_INVALID, "planes: MRT_PLANE_RGB, optionally | MRT_PLANE_ID | MRT_PLANE_T");
   if (!staging_dev || !frame_rgb_dev) return fail(ctx, MRT_ERR_INVALID, "staging and rgb frame buffers are required");
   if (width <= 0 || height <= 0) return fail(ctx, MRT_ERR_INVALID, "non-positive frame size");
@@ -815,14 +829,16 @@ int mrt_scatter_strips_planes(mrt_ctx *ctx, const void *staging_dev, void *frame
   std::memset(&S, 0, sizeof S);
   S.staging = (const uint32_t *)staging_dev;
   S.rgb = (uint32_t *)frame_rgb_dev; S.id = (uint32_t *)frame_id_dev; S.t = (uint32_t *)frame_t_dev;
-  S.W = width; S.H = height; S.nranks = num_ranks; S.strip_rows = strip_rows; S.skip_rank = skip_rank;
+  S.W = width; S.H = height; S.nranks = num_ranks; S.strip_rows = strip_rows;
+  S.skip_rank = skip_rank < 0 ? num_ranks : skip_rank; S.skip_span = skip_rank < 0 ? 0 : skip_span;
   S.has_id = (planes & MRT_PLANE_ID) ? 1 : 0; S.has_t = (planes & MRT_PLANE_T) ? 1 : 0;
   uint64_t off = 0;
   for (int r = 0; r < num_ranks; ++r) {
     p.rank = r;
     S.rank_rows[r] = local_rows_of(height, p);
     S.rank_off[r] = off;
-    if (r != skip_rank) off += (uint64_t)S.rank_rows[r] * (uint64_t)width * (uint64_t)plane_dwords(planes);
+    const bool skipped = skip_rank >= 0 && r >= skip_rank && r < skip_rank + skip_span;
+    if (!skipped) off += (uint64_t)S.rank_rows[r] * (uint64_t)width * (uint64_t)plane_dwords(planes);
   }
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   HIP_TRY(ctx, mrt::launch_scatter(S, (hipStream_t)stream));
@@ -1050,23 +1066,39 @@ int mrt_comm_destroy(mrt_comm *comm)
   return rc;
 }
 
-// scatter = false: the caller has a group open (the receives are only enqueued when it closes) and scatters itself
+// scatter = false: the caller has a group open (the receives are only enqueued when it closes) and scatters itself.
+// root_span: rank 0 has rendered the strips of that many shares of a partition into root_span + N - 1 (mrt_partition
+// {0, V, strip_rows, 1, root_span}) in place and rank r >= 1 sends the rows of share root_span + r - 1; 1 = the plain
+// partition into N.  Shares (the partition's "ranks") and real ranks only differ when root_span > 1.
 static int gather_strips(mrt_ctx *ctx, mrt_comm *comm, const void *packed_dev, void *staging_dev, void *frame_rgb_dev,
                          void *frame_id_dev, void *frame_t_dev, int32_t width, int32_t height, int32_t strip_rows,
-                         int32_t root_in_place, int32_t planes, void *stream, bool scatter)
+                         int32_t root_in_place, int32_t root_span, int32_t planes, void *stream, bool scatter)
 {
   if (!ctx || !comm) return MRT_ERR_INVALID;
   if (!planes_ok(planes)) return fail(ctx, MRT_ERR_INVALID, "planes: MRT_PLANE_RGB, optionally | MRT_PLANE_ID | MRT_PLANE_T");
   if (comm->ctx != ctx) return fail(ctx, MRT_ERR_INVALID, "mrt_gather_strips: the communicator belongs to another context");
   if (width <= 0 || height <= 0) return fail(ctx, MRT_ERR_INVALID, "non-positive frame size");
   const int N = comm->nranks, me = comm->rank;
-  mrt_partition p{me, N, strip_rows, 0};
+  if (root_span < 1 || (root_span > 1 && !root_in_place))
+    return fail(ctx, MRT_ERR_INVALID, "mrt_gather_strips: root_span >= 1, and more than one share only with rank 0 rendering in place");
+  const int V = N - 1 + root_span;             // shares of the partition
+  if (V > mrt::MAX_RANKS) return fail(ctx, MRT_ERR_TOO_LARGE, "more than 64 shares (ranks - 1 + root_span)");
+  auto share_of = [&](int r) { return r == 0 ? 0 : root_span + r - 1; }; // a real rank's (first) share
+  mrt_partition p{share_of(me), V, strip_rows, 0, me == 0 ? root_span : 1};
   if (!partition_ok(p)) return fail(ctx, MRT_ERR_INVALID, "bad strip partition");
   const Rccl *R = rccl(nullptr);
   if (!R) return fail(ctx, MRT_ERR_HIP, "RCCL is not open");
-  const int skip = root_in_place ? 0 : -1;
+  // per REAL rank: where its packed buffer lands in rank 0's staging area (rank order), and its length
   uint64_t off[mrt::MAX_RANKS], len[mrt::MAX_RANKS];
-  staging_layout(width, height, N, strip_rows, skip, plane_dwords(planes), off, len);
+  {
+    uint64_t o = 0;
+    for (int r = 0; r < N; ++r) {
+      mrt_partition q{share_of(r), V, strip_rows, 0, r == 0 ? root_span : 1};
+      off[r] = o;
+      len[r] = (r == 0 && root_in_place) ? 0 : (uint64_t)local_rows_of(height, q) * (uint64_t)width * (uint64_t)plane_dwords(planes);
+      o += len[r];
+    }
+  }
   hipStream_t st = (hipStream_t)stream;
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   if (me != 0) {
@@ -1091,8 +1123,8 @@ static int gather_strips(mrt_ctx *ctx, mrt_comm *comm, const void *packed_dev, v
   if (r1 != ncclSuccess) return rccl_fail(ctx, R, r1, "ncclSend / ncclRecv");
   if (r2 != ncclSuccess) return rccl_fail(ctx, R, r2, "ncclGroupEnd");
   if (!scatter) return MRT_OK;
-  return mrt_scatter_strips_planes(ctx, staging_dev, frame_rgb_dev, frame_id_dev, frame_t_dev, width, height, N, strip_rows, skip,
-                                   planes, stream);
+  return mrt_scatter_strips_span(ctx, staging_dev, frame_rgb_dev, frame_id_dev, frame_t_dev, width, height, V, strip_rows,
+                                 root_in_place ? 0 : -1, root_span, planes, stream);
 }
 
 int mrt_gather_strips(mrt_ctx *ctx, mrt_comm *comm, const void *packed_dev, void *staging_dev, void *frame_rgb_dev,
@@ -1100,7 +1132,7 @@ int mrt_gather_strips(mrt_ctx *ctx, mrt_comm *comm, const void *packed_dev, void
                       int32_t root_in_place, void *stream)
 {
   return gather_strips(ctx, comm, packed_dev, staging_dev, frame_rgb_dev, frame_id_dev, frame_t_dev, width, height,
-                       strip_rows, root_in_place, MRT_PLANES_ALL, stream, true);
+                       strip_rows, root_in_place, 1, MRT_PLANES_ALL, stream, true);
 }
 
 int mrt_gather_strips_planes(mrt_ctx *ctx, mrt_comm *comm, const void *packed_dev, void *staging_dev, void *frame_rgb_dev,
@@ -1108,7 +1140,15 @@ int mrt_gather_strips_planes(mrt_ctx *ctx, mrt_comm *comm, const void *packed_de
                              int32_t root_in_place, int32_t planes, void *stream)
 {
   return gather_strips(ctx, comm, packed_dev, staging_dev, frame_rgb_dev, frame_id_dev, frame_t_dev, width, height,
-                       strip_rows, root_in_place, planes, stream, true);
+                       strip_rows, root_in_place, 1, planes, stream, true);
+}
+
+int mrt_gather_strips_root(mrt_ctx *ctx, mrt_comm *comm, const void *packed_dev, void *staging_dev, void *frame_rgb_dev,
+                           void *frame_id_dev, void *frame_t_dev, int32_t width, int32_t height, int32_t strip_rows,
+                           int32_t root_span, int32_t planes, void *stream)
+{
+  return gather_strips(ctx, comm, packed_dev, staging_dev, frame_rgb_dev, frame_id_dev, frame_t_dev, width, height,
+                       strip_rows, 1, root_span, planes, stream, true);
 }
 
 int mrt_render_multi(mrt_ctx *const *ctxs, mrt_comm *const *comms, int32_t n, const mrt_camera *cam,
@@ -1179,7 +1219,7 @@ int mrt_render_multi(mrt_ctx *const *ctxs, mrt_comm *const *comms, int32_t n, co
       mrt_ctx *ctx = ctxs[r];
       void *staging = r == 0 ? (char *)ctx->out_mem + npix * 20 : nullptr;
       rc1 = gather_strips(ctx, comms[r], r == 0 ? nullptr : ctx->out_mem, staging, r == 0 ? A[0].rgb : nullptr,
-                          r == 0 ? A[0].id : nullptr, r == 0 ? A[0].t : nullptr, W, H, strip_rows, 1, planes, ctx->stream, false);
+                          r == 0 ? A[0].id : nullptr, r == 0 ? A[0].t : nullptr, W, H, strip_rows, 1, 1, planes, ctx->stream, false);
       if (rc1 != MRT_OK && r) fail(c0, rc1, ctx->err);
     }
     ncclResult_t r2 = R->GroupEnd();

@@ -144,7 +144,7 @@ __device__ __forceinline__ void render_bounce_body(const Args &S)
   const int lrow = tile_y * 8 + ty;
   const int lrow0 = tile_y * 8;
   const int strip = lrow0 / A.strip_rows;
-  const int grow0 = (strip * A.nranks + A.rank) * A.strip_rows + (lrow0 - strip * A.strip_rows);
+  const int grow0 = global_strip(strip, A.rank, A.nranks) * A.strip_rows + (lrow0 - strip * A.strip_rows);
   const int grow = grow0 + ty;
   const bool valid = (lrow < A.local_rows) && (grow < A.H) && (col < A.W);
 
@@ -857,7 +857,7 @@ __global__ __launch_bounds__(256) void bounce_weigh_kernel(SmallArgs S, uint32_t
   const int tile_y = tile / tiles_x, tile_x = tile - tile_y * tiles_x;
   const int lrow0 = tile_y * 8;
   const int strip = lrow0 / A.strip_rows;
-  const int grow0 = (strip * A.nranks + A.rank) * A.strip_rows + (lrow0 - strip * A.strip_rows);
+  const int grow0 = global_strip(strip, A.rank, A.nranks) * A.strip_rows + (lrow0 - strip * A.strip_rows);
   // candidates: the tile's cone against the spheres, the edge functions against the triangles (lane = primitive)
   bool pass = false;
   {

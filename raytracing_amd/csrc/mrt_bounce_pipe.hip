@@ -79,7 +79,7 @@ void render_bounce_pipe_kernel(SmallArgs S)
   const int lrow = tile_y * 8 + ty;
   const int lrow0 = tile_y * 8;
   const int strip = lrow0 / A.strip_rows;
-  const int grow0 = (strip * A.nranks + A.rank) * A.strip_rows + (lrow0 - strip * A.strip_rows);
+  const int grow0 = global_strip(strip, A.rank, A.nranks) * A.strip_rows + (lrow0 - strip * A.strip_rows);
   const int grow = grow0 + ty;
   const bool valid = (lrow < A.local_rows) && (grow < A.H) && (col < A.W);
   const int nsamp = MULTI ? A.spp : 1;

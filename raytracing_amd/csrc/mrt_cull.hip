@@ -302,7 +302,7 @@ void render_cull_kernel(RenderArgs A)
   // strips are multiples of 8 rows, so a tile never straddles two strips
   const int lrow0 = tile_y * 8;
   const int strip = lrow0 / A.strip_rows;
-  const int grow0 = (strip * A.nranks + A.rank) * A.strip_rows + (lrow0 - strip * A.strip_rows);
+  const int grow0 = global_strip(strip, A.rank, A.nranks) * A.strip_rows + (lrow0 - strip * A.strip_rows);
   const int grow = grow0 + ty;
   const bool valid_row = (lrow < A.local_rows) && (grow < A.H);
   bool valid[P];
@@ -1319,7 +1319,7 @@ __device__ __forceinline__ void bin_try_tile(const RenderArgs &A, int TW, int ti
 {
   // a rank of a partitioned frame only lists the tiles of its own strips (strips are multiples of 8 rows: a tile row
   // belongs to one strip)
-  if (A.nranks > 1 && ((ty * 8) / A.strip_rows) % A.nranks != A.rank) return;
+  if (A.nranks > 1 && !owns_strip((ty * 8) / A.strip_rows, A.rank, A.nranks)) return;
   const TileCone t = make_tile_cone(A.cam, A.W, A.H, A.cone_ext, tx, TW, ty * 8);
   if (!ball_may_touch_cone(wx, wy, wz, reff, t.cax, t.cay, t.caz, t.cosT, t.sinT)) return;
   const int n0 = bin_items0(A);
@@ -1432,7 +1432,7 @@ __global__ __launch_bounds__(256) void block_weight_kernel(RenderArgs A, int TW,
     const int tile_x = (b % bxn) * bs + (t & (bs - 1)), tile_y = (b / bxn) * bs + (t >> map);
     if (tile_x < txn && tile_y < tyn) {
       const int lrow0 = tile_y * 8, strip = lrow0 / A.strip_rows;
-      const int grow0 = (strip * A.nranks + A.rank) * A.strip_rows + (lrow0 - strip * A.strip_rows);
+      const int grow0 = global_strip(strip, A.rank, A.nranks) * A.strip_rows + (lrow0 - strip * A.strip_rows);
       if (grow0 < A.H) {
         const int gtile = (grow0 >> 3) * txn + tile_x;
         w = max(w, A.bin_cnt[BIN_HEAD + 2 * gtile] + A.bin_cnt[BIN_HEAD + 2 * gtile + 1]);

@@ -72,7 +72,7 @@ struct RenderArgs {
   DevScene sc;
   DevCamera cam;
   int32_t W, H;
-  int32_t rank, nranks, strip_rows; // strip partition
+  int32_t rank, nranks, strip_rows; // strip partition; rank: bits 0-15 the rank, bits 16-31 its span - 1 (global_strip below)
   int32_t local_rows;
   int32_t frame_layout;             // 0: buffers hold the rank's rows back to back; 1: whole frames, rows at their final place
   int32_t spp;                      // 1 or 121
@@ -117,6 +117,31 @@ struct RenderArgs {
   int32_t bin_clusters;                 // 0: the lists hold primitives; 1: leaf clusters of 64 (scenes of more primitives than tiles)
   int32_t solo_max;                     // teams dealing leaves: a tile with at most this many batches listed is rendered by member 0 alone
 };
+// A rank may render the strips of SPAN consecutive ranks of the partition (mrt_partition.rank_span: rank 0 of a weighted
+// multi-GPU frame takes several shares).  Its local strips, in ascending order, are the frame's strips s with
+// rank <= s % nranks < rank + span; RenderArgs.rank carries the span in its upper half.
+#if defined(__HIPCC__)
+__host__ __device__
+#endif
+inline int pack_rank(int rank, int span) { return rank | ((span > 1 ? span - 1 : 0) << 16); }
+#if defined(__HIPCC__)
+__host__ __device__
+#endif
+inline int global_strip(int local_strip, int packed_rank, int nranks)
+{
+  const int span = (packed_rank >> 16) + 1, rank = packed_rank & 0xffff;
+  if (span == 1) return local_strip * nranks + rank;
+  return (local_strip / span) * nranks + rank + local_strip % span;
+}
+#if defined(__HIPCC__)
+__host__ __device__
+#endif
+inline bool owns_strip(int strip, int packed_rank, int nranks)
+{
+  const int span = (packed_rank >> 16) + 1, rank = packed_rank & 0xffff, r = strip % nranks;
+  return r >= rank && r < rank + span;
+}
+
 // (SmallArgs below is at the 4 KB limit of a kernel's arguments, so the launcher-only options share team_mode's word:
 // bits 0-7 MRT_OPT_CULL_TEAM; bits 8-9 MRT_OPT_LISTS, 0 by the scene, 1 no lists at all (every tile walks), 2 lists of
 // primitives, 3 lists of leaf clusters; bits 16-30 MRT_OPT_LIST_CAP, > 0 (test hook) shortens every list to reach the
@@ -205,7 +230,7 @@ enum { MAX_RANKS = 64 };
 struct ScatterArgs {
   const uint32_t *staging;
   uint32_t *rgb, *id, *t;          // frame planes (id / t may be null)
-  int32_t W, H, nranks, strip_rows, skip_rank;
+  int32_t W, H, nranks, strip_rows, skip_rank, skip_span; // ranks skip_rank .. skip_rank + skip_span - 1 rendered in place
   int32_t has_id, has_t;           // which planes follow rgb in a packed buffer (MRT_PLANE_ID / MRT_PLANE_T)
   int32_t rank_rows[MAX_RANKS];    // rows of rank r
   uint64_t rank_off[MAX_RANKS];    // dword offset of rank r's packed buffer in staging

@@ -373,7 +373,7 @@ __global__ __launch_bounds__(256) void render_kernel(RenderArgs A)
   const int col0 = (blockIdx.x * 4 + wave) * (8 * P) + tx * P;
   const int lrow = blockIdx.y * 8 + ty;
   const int strip = lrow / A.strip_rows;
-  const int grow = (strip * A.nranks + A.rank) * A.strip_rows + (lrow - strip * A.strip_rows);
+  const int grow = global_strip(strip, A.rank, A.nranks) * A.strip_rows + (lrow - strip * A.strip_rows);
   const bool row_ok = (lrow < A.local_rows) && (grow < A.H);
 
   const int ns = sc.ns, nt = sc.nt;
@@ -757,7 +757,7 @@ __global__ __launch_bounds__(256) void scatter_kernel(ScatterArgs S)
 {
   const int strip = blockIdx.y;
   const int r = strip % S.nranks;
-  if (r == S.skip_rank) return; // rendered in place
+  if (r >= S.skip_rank && r < S.skip_rank + S.skip_span) return; // rendered in place
   const int row0 = strip * S.strip_rows;
   const int rows = row0 + S.strip_rows <= S.H ? S.strip_rows : S.H - row0;
   const size_t lrow0 = size_t(strip / S.nranks) * S.strip_rows; // the strip's first row in its rank's buffer

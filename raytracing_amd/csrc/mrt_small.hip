@@ -191,7 +191,7 @@ __device__ __forceinline__ void render_small_body(uint32_t wh, float cone_ext_s,
   if (cone_ext_s < 0.0f) {
     if (lrow0 >= A.local_rows) return;
     const int strip = lrow0 / A.strip_rows; // strips are multiples of 8 rows, LY divides 8: a tile never straddles two
-    grow0 = (strip * A.nranks + A.rank) * A.strip_rows + (lrow0 - strip * A.strip_rows);
+    grow0 = global_strip(strip, A.rank, A.nranks) * A.strip_rows + (lrow0 - strip * A.strip_rows);
   }
   const int grow = grow0 + ty;
   // u, v of the lane's pixels: tables hold float(i) / float(W) and float(i) / float(H) (uv_table_kernel); v is the

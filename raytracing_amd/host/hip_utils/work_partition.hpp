@@ -24,9 +24,10 @@ inline WorkPartition make_work_partition(std::size_t work_elements, std::size_t 
 }
 
 // strips of strip_rows rows dealt round-robin: strip s -> rank s % num_ranks
-inline mrt_partition make_strip_partition(int rank, int num_ranks, int strip_rows = 8)
+// (rank_span > 1: the strips of that many consecutive ranks in one render -- a weighted multi-GPU frame's rank 0)
+inline mrt_partition make_strip_partition(int rank, int num_ranks, int strip_rows = 8, int rank_span = 1)
 {
-  return mrt_partition{rank, num_ranks, strip_rows, 0};
+  return mrt_partition{rank, num_ranks, strip_rows, 0, rank_span};
 }
 
 } // namespace rt

@@ -25,9 +25,36 @@ def plane_dwords(planes=capi.PLANES_ALL):
     return 3 + (1 if planes & capi.PLANE_ID else 0) + (1 if planes & capi.PLANE_T else 0)
 
 
-def rank_rows(height, num_ranks, strip_rows=8):
+def share_partition(rank, num_ranks, root_share=1):
+    """(first share, shares, span) of a real rank when the frame is dealt in num_ranks - 1 + root_share shares and rank 0
+    renders the first root_share of them (include/mrt.h: mrt_gather_strips_root); root_share 1 = the plain partition."""
+    shares = num_ranks - 1 + root_share
+    return (0, shares, root_share) if rank == 0 else (root_share + rank - 1, shares, 1)
+
+
+def rank_rows(height, num_ranks, strip_rows=8, root_share=1):
     """Rows every rank renders."""
-    return [capi.local_rows(height, r, num_ranks, strip_rows) for r in range(num_ranks)]
+    out = []
+    for r in range(num_ranks):
+        first, shares, span = share_partition(r, num_ranks, root_share)
+        out.append(capi.local_rows(height, first, shares, strip_rows, span))
+    return out
+
+
+def suggest_root_share(render_ms_one_gpu, frame_bytes, num_ranks, link_gbps=45.0, max_shares=64):
+    """How many shares rank 0 should take when frames follow each other (exchange beside the next render): with k of
+    V = N - 1 + k shares, rank 0 renders k / V of the frame (render_ms_one_gpu * k / V) while it receives the other
+    (N - 1) / V of frame_bytes over its N - 1 links, each peer's 1 / V over that peer's own link at link_gbps
+    (xGMI: ~45-50 GB/s achievable per link) -- the frame costs the larger of the two; the smallest k that minimises it."""
+    if num_ranks <= 1:
+        return 1
+    best, best_t = 1, None
+    for k in range(1, max_shares - (num_ranks - 1) + 1):
+        v = num_ranks - 1 + k
+        t = max(render_ms_one_gpu * k / v, frame_bytes / v / (link_gbps * 1e6))
+        if best_t is None or t < best_t * 0.98:
+            best, best_t = k, t
+    return best
 
 
 def default_strip_rows(height, num_ranks):
@@ -38,11 +65,11 @@ def default_strip_rows(height, num_ranks):
     return max(8, (height // (num_ranks * 6)) // 8 * 8)
 
 
-def staging_offsets(height, width, num_ranks, strip_rows=8, skip_rank=0, planes=capi.PLANES_ALL):
+def staging_offsets(height, width, num_ranks, strip_rows=8, skip_rank=0, planes=capi.PLANES_ALL, root_share=1):
     """(offset, length) in 4-byte elements of every rank's packed buffer in rank 0's staging area (the layout
     mrt_scatter_strips reads); skip_rank has length 0."""
     out, off = [], 0
-    for r, rows in enumerate(rank_rows(height, num_ranks, strip_rows)):
+    for r, rows in enumerate(rank_rows(height, num_ranks, strip_rows, root_share)):
         n = 0 if r == skip_rank else rows * width * plane_dwords(planes)
         out.append((off, n))
         off += n
@@ -75,14 +102,17 @@ def exchange_packed(packed, staging, offsets, rank, num_ranks, dst=0, group=None
                 w.wait()
 
 
-def scatter_strips_host(staging, offsets, rgb, ids, tt, num_ranks, strip_rows=8, skip_rank=0, planes=capi.PLANES_ALL):
-    """numpy mirror of mrt_scatter_strips(_planes) (CPU tests of the N > 1 path): staging is a flat float32 array, the
-    frame planes are [H, W, 3] float32, [H, W] int32, [H, W] float32; a plane that does not travel is left alone."""
+def scatter_strips_host(staging, offsets, rgb, ids, tt, num_ranks, strip_rows=8, skip_rank=0, planes=capi.PLANES_ALL,
+                        root_share=1):
+    """numpy mirror of mrt_scatter_strips(_planes / _span) (CPU tests of the N > 1 path): staging is a flat float32
+    array, the frame planes are [H, W, 3] float32, [H, W] int32, [H, W] float32; a plane that does not travel is left
+    alone.  num_ranks: REAL ranks; with root_share > 1 rank r's rows are those of its share (share_partition)."""
     H, W = rgb.shape[:2]
     for r in range(num_ranks):
         if r == skip_rank:
             continue
-        rows = capi.local_row_index(H, r, num_ranks, strip_rows)
+        first, shares, span = share_partition(r, num_ranks, root_share)
+        rows = capi.local_row_index(H, first, shares, strip_rows, span)
         n, (o, _) = len(rows), offsets[r]
         rgb[rows] = staging[o:o + n * W * 3].reshape(n, W, 3)
         o += n * W * 3
@@ -101,15 +131,19 @@ class FrameRenderer:
     pipeline: frames in flight at N > 1.  1: render, then exchange, on one stream.  2 (default): two sets of buffers;
     the exchange (+ rank 0's scatter) of frame k runs on a side stream while frame k + 1 renders, with events between
     the two streams, so a stream of frames costs max(render, exchange) per frame, not the sum.  self.rgb / ids / tt
-    are the planes of the frame the last step() produced (complete once both streams have been synchronised)."""
+    are the planes of the frame the last step() produced (complete once both streams have been synchronised).
+    root_share: shares of the frame rank 0 renders when it is dealt in num_ranks - 1 + root_share shares (1: every
+    rank the same; more where the exchange, not the render, bounds the frame: suggest_root_share)."""
 
     def __init__(self, flat_scene, cam12, width, height, rank=0, num_ranks=1, device=0, strip_rows=None, spp=1,
-                 max_depth=0, planes=capi.PLANES_ALL, pipeline=2):
+                 max_depth=0, planes=capi.PLANES_ALL, pipeline=2, root_share=1):
         import torch
 
         self.torch = torch
         self.rank, self.num_ranks = rank, num_ranks
-        self.strip_rows = strip_rows or default_strip_rows(height, num_ranks)
+        self.root_share = 1 if num_ranks == 1 else max(1, min(int(root_share), 64 - (num_ranks - 1)))
+        self.part = share_partition(rank, num_ranks, self.root_share)   # (first share, shares, span)
+        self.strip_rows = strip_rows or default_strip_rows(height, self.part[1])
         self.W, self.H, self.spp, self.max_depth = width, height, spp, max_depth
         self.planes = capi.PLANES_ALL if num_ranks == 1 else (int(planes) | capi.PLANE_RGB)
         self.depth = 1 if num_ranks == 1 else max(1, min(2, int(pipeline)))
@@ -118,9 +152,10 @@ class FrameRenderer:
         torch.cuda.set_device(self.dev)
         self.ctx = capi.Context(device)
         self.ctx.upload(flat_scene)
-        self.local_rows = capi.local_rows(height, rank, num_ranks, self.strip_rows)
+        self.local_rows = capi.local_rows(height, self.part[0], self.part[1], self.strip_rows, self.part[2])
         self.stats = torch.zeros(8, dtype=torch.int64, device=self.dev)
-        self.offsets, total = staging_offsets(height, width, num_ranks, self.strip_rows, skip_rank=0, planes=self.planes)
+        self.offsets, total = staging_offsets(height, width, num_ranks, self.strip_rows, skip_rank=0, planes=self.planes,
+                                              root_share=self.root_share)
         has_id, has_t = bool(self.planes & capi.PLANE_ID), bool(self.planes & capi.PLANE_T)
         self.slots = []  # per frame in flight: dict(buf, rgb, ids, tt, staging)
         for _ in range(self.depth):
@@ -171,7 +206,8 @@ class FrameRenderer:
         """What is switched on, for the bench line."""
         names = ["rgb"] + (["id"] if self.planes & capi.PLANE_ID else []) + (["t"] if self.planes & capi.PLANE_T else [])
         return {"pipeline_depth": self.depth, "planes_gathered": "+".join(names),
-                "bytes_per_pixel_gathered": 4 * plane_dwords(self.planes), "weighted_partition": False}
+                "bytes_per_pixel_gathered": 4 * plane_dwords(self.planes), "weighted_partition": self.root_share > 1,
+                "root_share": f"{self.root_share} of {self.part[1]} shares" if self.num_ranks > 1 else None}
 
     def init_comm(self, unique_id):
         """Collective over the ranks: from now on the exchange step goes through mrt_gather_strips (RCCL behind the
@@ -188,8 +224,8 @@ class FrameRenderer:
         if s not in self._calls:  # argument structs are built once: a frame is tens of microseconds
             sl = self.slots[s]
             cam = capi.Camera.from12(self.cam12)
-            par = capi.Context._params(self.W, self.H, self.spp, self.max_depth, self.rank, self.num_ranks,
-                                       self.strip_rows, self.layout)
+            par = capi.Context._params(self.W, self.H, self.spp, self.max_depth, self.part[0], self.part[1],
+                                       self.strip_rows, self.layout, self.part[2])
             ptr = lambda x: C.c_void_p(x.data_ptr()) if x is not None else None
             self._calls[s] = (cam, par, C.byref(cam), C.byref(par), ptr(sl["rgb"]), ptr(sl["ids"]), ptr(sl["tt"]),
                               C.c_void_p(self.stats.data_ptr()))
@@ -217,15 +253,17 @@ class FrameRenderer:
             if self.rank == 0:
                 self.ctx.gather_strips(self.comm, None, ptr(sl["staging"]), ptr(sl["rgb"]), ptr(sl["ids"]), ptr(sl["tt"]),
                                        self.W, self.H, self.strip_rows, root_in_place=True, stream=stream,
-                                       planes=self.planes)
+                                       planes=self.planes, root_span=self.root_share)
             else:
                 self.ctx.gather_strips(self.comm, ptr(sl["buf"]), None, None, None, None, self.W, self.H,
-                                       self.strip_rows, root_in_place=True, stream=stream, planes=self.planes)
+                                       self.strip_rows, root_in_place=True, stream=stream, planes=self.planes,
+                                       root_span=self.root_share)
             return
         exchange_packed(sl["buf"] if self.rank else None, sl["staging"], self.offsets, self.rank, self.num_ranks, dst=0)
         if self.rank == 0:
             self.ctx.scatter_strips(ptr(sl["staging"]), ptr(sl["rgb"]), ptr(sl["ids"]), ptr(sl["tt"]), self.W, self.H,
-                                    self.num_ranks, self.strip_rows, skip_rank=0, stream=stream, planes=self.planes)
+                                    self.part[1], self.strip_rows, skip_rank=0, stream=stream, planes=self.planes,
+                                    skip_span=self.root_share)
 
     def step(self):
         """One frame: render local strips, send them to rank 0, rank 0 puts them in place.  Asynchronous; with

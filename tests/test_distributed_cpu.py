@@ -31,13 +31,15 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, strip, full, result_path):
+def _worker(rank, world, port, strip, full, result_path, root_share=1):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        rows = capi.local_row_index(H, rank, world, strip)
-        offsets, total = multigpu.staging_offsets(H, W, world, strip, skip_rank=0)
+        first, shares, span = multigpu.share_partition(rank, world, root_share)
+        rows = capi.local_row_index(H, first, shares, strip, span)
+        assert len(rows) == capi.local_rows(H, first, shares, strip, span)   # the C-ABI's count, the host mirror's rows
+        offsets, total = multigpu.staging_offsets(H, W, world, strip, skip_rank=0, root_share=root_share)
         if rank == 0:
             frame = {"rgb": np.zeros((H, W, 3), np.float32), "id": np.full((H, W), -9, np.int32),
                      "t": np.zeros((H, W), np.float32)}
@@ -46,7 +48,7 @@ def _worker(rank, world, port, strip, full, result_path):
             staging = torch.zeros(total, dtype=torch.float32)
             multigpu.exchange_packed(None, staging, offsets, rank, world, dst=0)
             multigpu.scatter_strips_host(staging.numpy(), offsets, frame["rgb"], frame["id"], frame["t"], world, strip,
-                                         skip_rank=0)
+                                         skip_rank=0, root_share=root_share)
             np.savez(result_path, **frame)
         else:
             n = len(rows) * W
@@ -71,6 +73,38 @@ def test_exchange_and_scatter_over_gloo(tmp_path, world, strip):
     got = np.load(out)
     for k in full:
         assert np.array_equal(got[k], full[k]), k
+
+
+@pytest.mark.parametrize("world,strip,root_share", [(2, 8, 3), (3, 8, 2), (4, 8, 4), (3, 16, 2)])
+def test_weighted_exchange_and_scatter_over_gloo(tmp_path, world, strip, root_share):
+    """Rank 0 takes root_share of world - 1 + root_share shares of the frame (mrt_partition.rank_span, rendered in place
+    in one go), every other rank one: same exchange, same scatter, same frame."""
+    r = O.Scene.default().render(O.default_viewport(W / H), W, H)
+    full = {k: r[k] for k in ("rgb", "id", "t")}
+    out = str(tmp_path / "frame.npz")
+    mp.spawn(_worker, args=(world, _free_port(), strip, full, out, root_share), nprocs=world, join=True)
+    got = np.load(out)
+    for k in full:
+        assert np.array_equal(got[k], full[k]), k
+
+
+def test_root_share_partition_and_suggestion():
+    # every row belongs to exactly one rank, rank 0 holds its shares' strips in ascending order
+    for Hh, n, strip, k in ((1080, 8, 8, 57), (52, 3, 8, 2), (2160, 4, 16, 5), (270, 2, 8, 63)):
+        seen = np.zeros(Hh, np.int32)
+        for r in range(n):
+            first, shares, span = multigpu.share_partition(r, n, k)
+            rows = capi.local_row_index(Hh, first, shares, strip, span)
+            assert len(rows) == capi.local_rows(Hh, first, shares, strip, span) and np.all(np.diff(rows) > 0)
+            seen[rows] += 1
+        assert np.all(seen == 1)
+        assert sum(multigpu.rank_rows(Hh, n, strip, k)) == Hh
+    # the default frame: 16 us on one GPU, 41.5 MB to gather -- rank 0 should take nearly everything; a frame of 3 ms
+    # and the same bytes should be dealt evenly
+    assert multigpu.suggest_root_share(0.016, 41.5e6, 8) >= 40
+    assert multigpu.suggest_root_share(0.016, 41.5e6, 2) >= 40
+    assert multigpu.suggest_root_share(3.3, 42e6, 8) == 1
+    assert multigpu.suggest_root_share(1.0, 1e6, 1) == 1
 
 
 def test_staging_layout_and_strip_choice():

@@ -1154,6 +1154,58 @@ def test_device_render_frame_layout_and_strip_scatter(gpu_ctx, W, H, nranks, str
     assert all(np.array_equal(h[k], full[k]) for k in h)
 
 
+@pytest.mark.parametrize("scene,W,H,nranks,strip,share,kw", [
+    ("default", 320, 200, 3, 8, 4, {}), ("default", 250, 130, 2, 16, 3, {}), ("default", 96, 52, 4, 8, 2, {"spp": 121}),
+    ("default", 128, 72, 3, 8, 5, {"max_depth": 3}), ("default", 64, 40, 2, 8, 3, {"max_depth": 8, "spp": 121}),
+    ("large", 203, 149, 3, 8, 3, {}), ("large", 120, 90, 2, 8, 6, {"max_depth": 2})])
+def test_weighted_partition_rank_span(gpu_ctx, kernel_mode, scene, W, H, nranks, strip, share, kw):
+    """mrt_partition.rank_span: rank 0 renders `share` of the nranks - 1 + share shares of a frame in ONE call, in place
+    (frame_layout 1), every other rank one share into its packed buffer; mrt_scatter_strips_span puts those in place.
+    Frame == the 1-GPU frame, bitwise, under every render kernel, at 121 samples and with bounce chains (a pixel's
+    random stream is its index in the FULL frame whatever the shares)."""
+    torch = pytest.importorskip("torch")
+    from raytracing_amd import multigpu
+    if scene == "default":
+        flat, _ = scenes.default_scene()
+        cam = capi.default_viewport(W / H)
+    else:
+        spec = _random_scene(1271, 200, 4000)
+        flat, cam = spec.flatten(), spec.cam12(W / H)
+    gpu_ctx.upload(flat)
+    full = gpu_ctx.render(cam, W, H, **kw)
+    dev = torch.device("cuda:0")
+    n = W * H
+    frame = torch.full((n * 5,), -3.0, dtype=torch.float32, device=dev)
+    rgb, ids, tt = frame[:n * 3], frame[n * 3:n * 4].view(torch.int32), frame[n * 4:]
+    offsets, total = multigpu.staging_offsets(H, W, nranks, strip, skip_rank=0, root_share=share)
+    staging = torch.zeros(max(total, 1), dtype=torch.float32, device=dev)
+    stream = torch.cuda.current_stream().cuda_stream
+    shares = nranks - 1 + share
+    gpu_ctx.render_device(cam, W, H, rgb.data_ptr(), id_ptr=ids.data_ptr(), t_ptr=tt.data_ptr(), stream=stream,
+                          rank=0, num_ranks=shares, strip_rows=strip, frame_layout=1, rank_span=share, **kw)
+    for rank in range(1, nranks):
+        o, ln = offsets[rank]
+        first, _, span = multigpu.share_partition(rank, nranks, share)
+        rows = capi.local_rows(H, first, shares, strip, span)
+        assert ln == rows * W * 5
+        if rows == 0:
+            continue
+        gpu_ctx.render_device(cam, W, H, staging[o:].data_ptr(), id_ptr=staging[o + rows * W * 3:].data_ptr(),
+                              t_ptr=staging[o + rows * W * 4:].data_ptr(), stream=stream, rank=first, num_ranks=shares,
+                              strip_rows=strip, **kw)
+    gpu_ctx.scatter_strips(staging.data_ptr(), rgb.data_ptr(), ids.data_ptr(), tt.data_ptr(), W, H, shares, strip,
+                           skip_rank=0, stream=stream, skip_span=share)
+    torch.cuda.synchronize()
+    assert np.array_equal(rgb.view(H, W, 3).cpu().numpy(), full["rgb"])
+    assert np.array_equal(ids.view(H, W).cpu().numpy(), full["id"])
+    assert np.array_equal(tt.view(H, W).cpu().numpy(), full["t"])
+    # the blocking entry point with a span: the local rows of rank 0, back to back
+    part = gpu_ctx.render(cam, W, H, rank=0, num_ranks=shares, strip_rows=strip, rank_span=share, **kw)
+    rows0 = capi.local_row_index(H, 0, shares, strip, share)
+    for k in ("rgb", "id", "t"):
+        assert np.array_equal(part[k], full[k][rows0]), k
+
+
 def test_frame_layout_under_every_kernel_and_bounces(gpu_ctx):
     """frame_layout 1 writes a rank's rows at their final places, under every render kernel and the bounce kernel;
     the rows of other ranks are not touched."""

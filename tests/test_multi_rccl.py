@@ -165,3 +165,34 @@ def test_render_multi_one_context_matches_render(gpu_ctx, scene):
     # the frame goes on living in the context's buffer: a plain render afterwards must not be disturbed by it
     again = gpu_ctx.render(cam, W, H, max_depth=depth)
     assert np.array_equal(again["rgb"], full["rgb"])
+
+
+def test_gather_strips_root_single_rank(gpu_ctx):
+    """mrt_gather_strips_root on a communicator of one rank: the root renders all root_span shares in place in one call
+    (mrt_partition.rank_span) and there is nobody to receive from; and its argument checks."""
+    torch = pytest.importorskip("torch")
+    W, H, strip, span = 200, 136, 8, 3
+    flat, _ = scenes.default_scene()
+    gpu_ctx.upload(flat)
+    cam = capi.default_viewport(W / H)
+    full = gpu_ctx.render(cam, W, H)
+    comm = capi.Comm(gpu_ctx, capi.comm_unique_id(), 0, 1)
+    try:
+        _, rgb, ids, tt = _frame_buffers(torch, W, H)
+        stream = torch.cuda.current_stream().cuda_stream
+        gpu_ctx.render_device(cam, W, H, rgb.data_ptr(), id_ptr=ids.data_ptr(), t_ptr=tt.data_ptr(), stream=stream,
+                              rank=0, num_ranks=span, strip_rows=strip, frame_layout=1, rank_span=span)
+        gpu_ctx.gather_strips(comm, None, None, rgb.data_ptr(), ids.data_ptr(), tt.data_ptr(), W, H, strip_rows=strip,
+                              root_in_place=True, stream=stream, root_span=span)
+        torch.cuda.synchronize()
+        assert np.array_equal(rgb.view(H, W, 3).cpu().numpy(), full["rgb"])
+        assert np.array_equal(ids.view(H, W).cpu().numpy(), full["id"])
+        assert np.array_equal(tt.view(H, W).cpu().numpy(), full["t"])
+        with pytest.raises(capi.MrtError):   # more than 64 shares
+            gpu_ctx.gather_strips(comm, None, None, rgb.data_ptr(), ids.data_ptr(), tt.data_ptr(), W, H, strip_rows=strip,
+                                  root_in_place=True, stream=stream, root_span=65)
+        with pytest.raises(capi.MrtError):   # a span that runs past the partition
+            gpu_ctx.render_device(cam, W, H, rgb.data_ptr(), stream=stream, rank=2, num_ranks=3, strip_rows=strip,
+                                  rank_span=2)
+    finally:
+        comm.close()

@@ -81,6 +81,24 @@ def test_bench_picture_only_gather_and_both_pipeline_depths(tmp_path, pipeline):
     assert np.array_equal(fn["rgb"], f1["rgb"]) and "id" not in fn.files
 
 
+@pytest.mark.timeout(400)
+@pytest.mark.parametrize("n,share", [(2, "1"), (3, "5"), (2, "63"), (4, "auto")])
+def test_bench_weighted_partition(tmp_path, n, share):
+    """--root-share K: rank 0 renders K of N - 1 + K shares of the frame in place (one render, mrt_partition.rank_span),
+    the others one share each; auto picks K from the one-GPU frame time against the bytes to gather.  The frame that
+    arrives is the 1-GPU frame whatever the shares."""
+    one, f1, _ = _bench(tmp_path, 1, "C2")
+    js, fn, _ = _bench(tmp_path, n, "C2", extra=("--root-share", share))
+    mg = js["multi_gpu"]
+    if share != "auto":
+        assert mg["weighted_partition"] == (share != "1") and mg["root_share"] == f"{share} of {n - 1 + int(share)} shares"
+    else:
+        assert "auto" in mg["root_share_how"]
+    assert js["frame_check"]["ok"], js["frame_check"]
+    for k in ("rgb", "id", "t"):
+        assert np.array_equal(fn[k], f1[k]), (n, share, k)
+
+
 @pytest.mark.timeout(300)
 def test_bench_falls_back_when_the_ranks_cannot_form_a_communicator(tmp_path):
     """The communicator set-up of the N > 1 bench on one GPU: rank 0 makes the id, torch.distributed hands it round,
