@@ -230,6 +230,152 @@ __device__ __forceinline__ bool triangle_may_be_hit(const DevScene &sc, const De
   return true;
 }
 
+// ---- triangle set-up: the edge functions of every triangle at the frame's pixels, once per frame ------------------
+// PAIRS (render_cull_kernel, frames of ONE ray per pixel).  The refinement above asks whether any ray of a tile's
+// pyramid can be accepted; the same three functions sgn w_e.d, affine in a pixel's column and row, also say WHICH pixels
+// can -- if they are sharp enough to tell which of a tile's rays a sliver on a horizon lies between.  In fp32 and per
+// tile they are not: w_e.d cancels to 1e-5 of its terms on a grazing terrain and a pixel column is 3e-6 of them.  So a
+// kernel of its own works them out once per frame and triangle (lane = triangle), in DOUBLE from the fp32 record and
+// the camera (exact for the purpose), relative to a reference pixel next to the triangle so that fp32 carries them
+// from there:
+//   per edge e:  value at the reference pixel, step per column, step per row, error bound
+//   per triangle: the reference pixel (column, row), the nearest an accepted hit can be, valid
+// and a tile evaluates value + (column - ref) step + (row - ref) step in two FMAs.  Three things keep the bound small:
+//  * the sign of n.d is the NUMERATOR's: the exact test wants t = (k - n.o) / (n.d) >= 0.01, so on every ray it accepts
+//    n.d has the sign of k - n.o -- it need not be the same over a whole tile (on a hill's silhouette it is not);
+//  * the directions of accepted rays come from the triangle's BOUNDING BALL (the hit point lies in the accepted region,
+//    mrt_scene_build.h tri_bound): |m.d|, |n.d| and the |t| |d| that multiplies the rounding of n.d are bounded over
+//    the rays through the ball, not over a tile's cone -- where min |n.d| is zero on a silhouette;
+//  * a pixel's own fp32 ray ((ul + u h) + v vv) - o, u = col / W, v = row / H rounds seven times (u, u h, the sum, v,
+//    v vv, the sum, the difference), in component k by at most 2^-24 (3 |ul_k| + 5 |h_k| + 4 |v_k| + |o_k|) =: r_k, and
+//    enters as sum_k |w_k| r_k (taken 1.5 times) instead of |w|1 times a bound over the whole camera.
+// What is left is the exact test's own rounding in e, times |n.d| <= big |d| (first order, u = 2^-24, five times over;
+// N1 = |k| + |n|1 |o|1, t (n.d) = num):
+//   t = fl(num / n.d), num off by 4u N1, n.d by 3u |n|1 |d|   ->  |dt| |n.d| <= 4u N1 + 3u |n|1 |t| |d| + u |num|, which
+//                                                                 moves p ALONG the ray: e by |m.d| |dt|
+//   p = fl(o + fl(t d)), e = fl(fl(m.p) - c)                  ->  5u |m|1 |t| |d| + 4u |m|1 |o|1 + 2u |c|
+//   u [ |m.d| (8 N1 + 2 |num| + 3.5 |n|1 |t| |d|) + |d| (5 |m|1 |num| + 5 big (|m|1 |o|1 + |c|)) ] + 1e-6 big |d|
+// A triangle whose plane holds the camera (to rounding: no sign to go by) is not valid (.w = 0): the tile refines it as
+// above and tests it for all pixels.  One without a finite bound (the loose triangles: .w = 2) gets its values, steps and
+// the rays' part of the bound here and the exact test's part from the tile, over the tile's cone (setup_bound_at_tile).
+struct SetupCam {
+  double ul[3], h[3], v[3], o[3];   // the camera, ray(col, row) = ul + (col / W) h + (row / H) v - o
+  double inv[3][3];                 // rows: the dual basis of (h, v, ul - o) -- a direction's (alpha, beta, gamma)
+  double rW, rH;
+  float r[3];                       // rounding of a pixel's ray per component (above), taken 1.5 times
+  float dl;                         // max |ray| over the frame, rounded up
+  int W, H;
+};
+enum { SETUP_FLOATS = 16 };
+__global__ __launch_bounds__(256) void tri_setup_kernel(DevScene sc, SetupCam C, float4 *__restrict__ out)
+{
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= sc.nt) return;
+  const float4 *r4 = reinterpret_cast<const float4 *>(sc.tri_rec + 16 * size_t(i));
+  const float4 q0 = r4[0];
+  const float ox = float(C.o[0]), oy = float(C.o[1]), oz = float(C.o[2]);
+  const float num = q0.w - dot3(ox, oy, oz, q0.x, q0.y, q0.z); // the exact test's own numerator
+  const float anum = fabsf(num), pn1 = norm1(q0.x, q0.y, q0.z), o1 = norm1(ox, oy, oz);
+  const float N1 = fabsf(q0.w) + pn1 * o1;
+  const float R = sc.tri_br[i];
+  float4 *w4 = out + 4 * size_t(i);
+  const bool valid = anum > 1e-4f * N1; // (NaN: not valid)
+  const bool ball = R < 3.0e38f;         // false: no finite bound -- the tile works out the part of the bound that wants one
+  if (!valid) {
+    w4[0] = make_float4(0, 0, 0, 0); w4[1] = w4[0]; w4[2] = w4[0]; w4[3] = make_float4(0, 0, 0, 0); // .w == 0: not valid
+    return;
+  }
+  const double sgn = num > 0.0f ? 1.0 : -1.0;
+  // the ball: direction to its centre, the angle it is seen under, the farthest an accepted hit can be
+  const double bx = double(sc.tri_bx[i]) - C.o[0], by = double(sc.tri_by[i]) - C.o[1], bz = double(sc.tri_bz[i]) - C.o[2];
+  const double L = sqrt(bx * bx + by * by + bz * bz);
+  const double Rp = ball ? double(R) * 1.01 + 4e-7 * (L + double(o1)) + 1e-30 : 0.0; // (a hit point is itself rounded)
+  const double sinb = ball && L > Rp ? Rp / L : 1.0;
+  const double far = (L + Rp) * 1.01;
+  // reference pixel: where the ball's centre is seen, or the frame's middle when it is behind the camera
+  double col = 0.5 * C.W, row = 0.5 * C.H;
+  {
+    const double al = C.inv[0][0] * bx + C.inv[0][1] * by + C.inv[0][2] * bz, be = C.inv[1][0] * bx + C.inv[1][1] * by + C.inv[1][2] * bz,
+                 ga = C.inv[2][0] * bx + C.inv[2][1] * by + C.inv[2][2] * bz;
+    if (ga > 0.0) {
+      const double c0 = al / ga * C.W, r0 = be / ga * C.H;
+      if (fabs(c0) < 1e6 && fabs(r0) < 1e6) { col = rint(c0); row = rint(r0); }
+    }
+  }
+  const double u = col * C.rW, v = row * C.rH;
+  const double dx = __builtin_fma(v, C.v[0], __builtin_fma(u, C.h[0], C.ul[0])) - C.o[0],
+               dy = __builtin_fma(v, C.v[1], __builtin_fma(u, C.h[1], C.ul[1])) - C.o[1],
+               dz = __builtin_fma(v, C.v[2], __builtin_fma(u, C.h[2], C.ul[2])) - C.o[2];
+  const double nx = q0.x, ny = q0.y, nz = q0.z;
+  const double num64 = double(q0.w) - (C.o[0] * nx + C.o[1] * ny + C.o[2] * nz);
+  const double n2 = sqrt(nx * nx + ny * ny + nz * nz);
+  const double invL = L > 0.0 ? 1.0 / L : 0.0;
+  // max |n.u| over the unit directions through the ball
+  const double big = fmin(n2, fabs(nx * bx + ny * by + nz * bz) * invL + n2 * sinb) * 1.001;
+  const float dl = C.dl;
+  float tn = float(fabs(num64) / (big > 0.0 ? big : 1e-300) * (1.0 - 1e-6)); // |t| |d| of an accepted ray is at least this
+  float4 o4[3];
+#pragma unroll
+  for (int e = 0; e < 3; ++e) {
+    const float4 qe = r4[1 + e];
+    const double mx = qe.x, my = qe.y, mz = qe.z;
+    const double a = (mx * C.o[0] + my * C.o[1] + mz * C.o[2]) - double(qe.w);
+    const double wx = a * nx + num64 * mx, wy = a * ny + num64 * my, wz = a * nz + num64 * mz;
+    const double S = sgn * (wx * dx + wy * dy + wz * dz);
+    const double Hs = sgn * (wx * C.h[0] + wy * C.h[1] + wz * C.h[2]) * C.rW, Vs = sgn * (wx * C.v[0] + wy * C.v[1] + wz * C.v[2]) * C.rH;
+    const double m2 = sqrt(mx * mx + my * my + mz * mz), m1 = fabs(mx) + fabs(my) + fabs(mz);
+    const double md = double(dl) * fmin(m2, fabs(mx * bx + my * by + mz * bz) * invL + m2 * sinb) * 1.001; // |m.d| on accepted rays
+    const double E = 1.02 * (fabs(wx) * C.r[0] + fabs(wy) * C.r[1] + fabs(wz) * C.r[2]);
+    const double own = double(MRT_REFINE_U) * (md * (8.0 * N1 + 2.0 * anum + 3.5 * pn1 * far) +
+                                               double(dl) * (5.0 * m1 * anum + 5.0 * big * (m1 * o1 + fabs(double(qe.w))))) +
+                       1e-6 * big * dl;
+    const double err = (ball ? E + own : E) * 1.0001;
+    o4[e] = make_float4(float(S), float(Hs), float(Vs), float(err) * (1.0f + 1e-6f) + 1e-37f);
+  }
+  w4[0] = o4[0]; w4[1] = o4[1]; w4[2] = o4[2];
+  w4[3] = make_float4(float(col), float(row), ball ? tn : 0.0f, ball ? 1.0f : 2.0f);
+}
+
+// The exact test's part of the bound for a triangle without a bounding ball, over a tile's cone instead (the terms of
+// tri_setup_kernel with |m.d|, max |n.u| and |t| |d| = |num| / min |n.u| taken over the tile).  own[e] per edge; false:
+// no ray of the tile is accepted (the plane tests of triangle_may_be_hit (1)); own = +inf when n.d changes sign over
+// the tile (nothing to go by).
+__device__ __forceinline__ bool setup_bound_at_tile(const DevScene &sc, const DevCamera &cam, const ConeBound &C, int i, float own[3])
+{
+  const float4 *r4 = reinterpret_cast<const float4 *>(sc.tri_rec + 16 * size_t(i));
+  const float4 q0 = r4[0];
+  const float num = q0.w - dot3(cam.ox, cam.oy, cam.oz, q0.x, q0.y, q0.z);
+  const float anum = fabsf(num), pn1 = norm1(q0.x, q0.y, q0.z), o1 = norm1(cam.ox, cam.oy, cam.oz);
+  const float N1 = fabsf(q0.w) + pn1 * o1;
+  const float c = bdot3(q0.x, q0.y, q0.z, C.cax, C.cay, C.caz);
+  const float qx = __builtin_fmaf(-c, C.cax, q0.x), qy = __builtin_fmaf(-c, C.cay, q0.y), qz = __builtin_fmaf(-c, C.caz, q0.z);
+  const float sp = fast_sqrt(bdot3(qx, qy, qz, qx, qy, qz));
+  const float slack = 2e-5f * pn1;
+  const float ccos = c * C.cosT;
+  const float lo = __builtin_fmaf(-sp, C.sinT, ccos) - slack, hi = __builtin_fmaf(sp, C.sinT, ccos) + slack;
+  own[0] = own[1] = own[2] = MRT_INF;
+  if (!(C.cosT > 0.0f && (lo > 0.0f || hi < 0.0f))) return true;
+  const bool inside = sp * C.cosT <= fabsf(c) * C.sinT * 1.01f + slack;
+  const float big = inside ? pn1 : fmaxf(fabsf(lo), fabsf(hi));
+  const bool behind = (lo > 0.0f) ? (num < 0.0f) : (num > 0.0f);
+  if (behind && anum > 1e-4f * N1) return false;
+  if (anum * (1.0f - 1e-4f) > C.reach_max * big) return false;
+  const float dl = C.dlen_max * 1.01f;
+  const float far = anum * fast_rcp(fminf(fabsf(lo), fabsf(hi))) * 1.01f;
+#pragma unroll
+  for (int e = 0; e < 3; ++e) {
+    const float4 qe = r4[1 + e];
+    const float m1 = norm1(qe.x, qe.y, qe.z);
+    const float md = (fabsf(bdot3(qe.x, qe.y, qe.z, C.dcx, C.dcy, C.dcz)) + fabsf(bdot3(qe.x, qe.y, qe.z, C.ehx, C.ehy, C.ehz)) +
+                      fabsf(bdot3(qe.x, qe.y, qe.z, C.evx, C.evy, C.evz))) * 1.001f;
+    own[e] = __builtin_fmaf(MRT_REFINE_U,
+                 __builtin_fmaf(md, __builtin_fmaf(3.5f * pn1, far, __builtin_fmaf(8.0f, N1, 2.0f * anum)),
+                     dl * __builtin_fmaf(5.0f * big, __builtin_fmaf(m1, o1, fabsf(qe.w)), 5.0f * m1 * anum)),
+                 1e-6f * big * dl) * 1.0001f;
+  }
+  return true;
+}
+
 template <bool HIER, int P, bool MULTI, int NW, bool LSPLIT = false>
 #ifndef MRT_CULL_SINGLE_WAVES
 #define MRT_CULL_SINGLE_WAVES 1 // (experiment: 8 forces the one-wave-per-tile, one-sample kernel into 64 registers)
@@ -262,6 +408,21 @@ void render_cull_kernel(RenderArgs A)
   // reloaded for every light (96 B per lane, 0.37 GB of scratch writes per C5 frame)
   __shared__ float tm_pre[LSPLIT ? NWS * PRE_LPP * 16 : 1];
   const int member = NW > 1 ? wave : 0;
+  // PAIRS (triangle_batch below): the edge functions of a batch's survivors at the tile's pixels, [wave][survivor][12],
+  // and the pixels' lists of triangles still to be tested, [wave][entry][pixel]
+  constexpr bool PAIRS = HIER && P == 1 && !MULTI && NW > 1 && !LSPLIT; // (a wave on its own: 25 more registers, a wave per SIMD less -- 10k spheres 0.32 -> 0.38 ms)
+  constexpr int PK_WAVES = NWS;
+  constexpr int PK_CAP = 4;
+  constexpr int PK_SLOTS = 16;
+  __shared__ float4 pk_fn[PAIRS ? PK_WAVES * PK_SLOTS * 3 : 1];
+  __shared__ uint32_t pk_list[PAIRS ? PK_WAVES * PK_CAP * 64 : 1];
+  constexpr int PK_FAT = 32;                 // a triangle that more pixels than this cannot exclude is tested the usual way
+  // (the set-up lives behind RenderArgs.utab, which only the small-scene kernel reads: the arguments are at their 4 KB limit)
+  [[maybe_unused]] const float4 *tri_setup = PAIRS ? reinterpret_cast<const float4 *>(A.utab) : nullptr;
+  [[maybe_unused]] const bool pairs_on = PAIRS && tri_setup != nullptr; // no set-up (no scratch: the allocation-free entry point): the usual way
+  [[maybe_unused]] const int wslot = wave;
+  [[maybe_unused]] int pk_n = 0;              // triangles in this pixel's list
+  [[maybe_unused]] const float pk_a = float(tx) - 3.5f, pk_b = float(ty) - 3.5f; // the pixel's column / row from the tile's centre ray
 
   // 2-D grid: blockIdx.y = tile row, blockIdx.x*4 + wave = tile column (both wave-uniform, so the strip
   // arithmetic below runs on the scalar unit); a team's tile column is its workgroup's index
@@ -520,45 +681,161 @@ void render_cull_kernel(RenderArgs A)
     // one batch of up to 64 candidate triangles, lane = triangle i (pass: the lane has one): refinement when the
     // batch is crowded, then the exact test of every survivor for all pixels
     // (base >= 0: lane's triangle is base + lane, a leaf of the hierarchy; base < 0: the lanes' triangles come from a list)
-    auto triangle_batch = [&](int i, bool pass, int base) {
+    // PAIRS.  On a terrain seen at a grazing angle a tile's candidates are slivers that each cover a few of its 64 pixels
+    // (1M triangles at 4K: 79 survive the refinement per tile, 43 of the tile's pixels hit anything), and the exact
+    // test of ONE triangle for all 64 pixels spends 60 instructions on four useful lanes.  So the pixels keep lists:
+    // the refinement hands back its edge functions at the tile's pixels (affine in column and row, with the error
+    // bound that makes them conservative), every pixel evaluates them for each survivor -- six FMAs -- and notes the
+    // triangles it cannot exclude; then every lane runs the exact test of ITS OWN next triangle, 64 different
+    // (pixel, triangle) pairs per pass.  The closest-hit rule is an order-independent minimum over (t, object), so the
+    // result is the same to the bit.  A team member notes pairs until a pixel's list is full or its leaves are dealt
+    // with.  (Teams only: a wave on its own would want the hits after every batch for its depth bound, and the 25
+    // registers this costs take a wave per SIMD from the scenes that have no triangles at all.)
+    // the exact test of triangle tj (wave-uniform) for all pixels of the tile; true in the lanes it moved
+    auto exact_pass = [&](int tj) __attribute__((always_inline)) {
       bool moved = false;
-      if (HIER && __popcll(__ballot(pass)) >= TRI_REFINE_MIN && pass) {
-        ConeBound CB;
-        CB.cax = cax; CB.cay = cay; CB.caz = caz; CB.cosT = cosT; CB.sinT = sinT;
-        CB.dcx = dcx; CB.dcy = dcy; CB.dcz = dcz;
-        CB.ehx = ehx; CB.ehy = ehy; CB.ehz = ehz; CB.evx = evx; CB.evy = evy; CB.evz = evz;
-        CB.cam_round = cam_round; CB.dlen_max = dlen_max; CB.reach_max = reach_max;
-        pass = base >= 0 ? triangle_may_be_hit<false>(sc, cam, CB, i) : triangle_may_be_hit<true>(sc, cam, CB, i);
+      const float *q = sc.tri_rec + 16 * size_t(tj);   // wave-uniform address: one s_load_dwordx16
+      const float pnx = q[0], pny = q[1], pnz = q[2], kp = q[3];
+      const float num = kp - dot3(cam.ox, cam.oy, cam.oz, pnx, pny, pnz);
+      const int obj = sc.tri_obj[tj];
+#pragma unroll
+      for (int p = 0; p < P; ++p) {
+        const float rdn = dot3(dx[p], dy[p], dz[p], pnx, pny, pnz);
+        const float t = num / rdn;
+        // the three edge tests only matter in lanes whose t is in range and could still win; no such lane
+        // in the wave (the triangle lies behind what the tile already hit, or behind the camera): skip them
+        const bool cand = (rdn != 0.0f) & (0.01f <= t) & (t <= best_t[p]);
+        if (!__any(cand)) continue;
+        const float px = cam.ox + t * dx[p], py = cam.oy + t * dy[p], pz = cam.oz + t * dz[p];
+        const float e0 = dot3(q[4], q[5], q[6], px, py, pz) - q[7];
+        const float e1 = dot3(q[8], q[9], q[10], px, py, pz) - q[11];
+        const float e2 = dot3(q[12], q[13], q[14], px, py, pz) - q[15];
+        const bool hit = (rdn != 0.0f) & (e0 > -1e-6f) & (e1 > -1e-6f) & (e2 > -1e-6f) & (0.01f <= t) & (t <= MRT_INF);
+        if (hit) {
+          if (t < best_t[p] || (t == best_t[p] && t < MRT_INF && obj < best_obj[p])) {
+            best_t[p] = t; best_obj[p] = obj; best_prim[p] = ns + tj; moved = true;
+          }
+        }
       }
+      return moved;
+    };
+    auto pk_flush = [&]() __attribute__((always_inline)) {
+      if constexpr (PAIRS) {
+        for (int s = 0; s < PK_CAP; ++s) {
+          const bool act = s < pk_n;
+          if (!__any(act)) break;
+          if (act) {
+            const int tj = int(pk_list[(wslot * PK_CAP + s) * 64 + lane]);
+            const float4 *r4 = reinterpret_cast<const float4 *>(sc.tri_rec + 16 * size_t(tj)); // the lane's own record
+            const float4 q0 = r4[0];
+            const float num = q0.w - dot3(cam.ox, cam.oy, cam.oz, q0.x, q0.y, q0.z);
+            const float rdn = dot3(dx[0], dy[0], dz[0], q0.x, q0.y, q0.z);
+            const float t = num / rdn;
+            if ((rdn != 0.0f) & (0.01f <= t) & (t <= best_t[0])) { // (a lane whose t cannot win skips the edges)
+              const float4 q1 = r4[1], q2 = r4[2], q3 = r4[3];
+              const float px = cam.ox + t * dx[0], py = cam.oy + t * dy[0], pz = cam.oz + t * dz[0];
+              const float e0 = dot3(q1.x, q1.y, q1.z, px, py, pz) - q1.w;
+              const float e1 = dot3(q2.x, q2.y, q2.z, px, py, pz) - q2.w;
+              const float e2 = dot3(q3.x, q3.y, q3.z, px, py, pz) - q3.w;
+              if ((e0 > -1e-6f) & (e1 > -1e-6f) & (e2 > -1e-6f) & (t <= MRT_INF)) {
+                const int obj = sc.tri_obj[tj];
+                if (t < best_t[0] || (t == best_t[0] && t < MRT_INF && obj < best_obj[0])) {
+                  best_t[0] = t; best_obj[0] = obj; best_prim[0] = ns + tj;
+                }
+              }
+            }
+          }
+        }
+        pk_n = 0;
+      }
+    };
+    auto triangle_batch = [&](int i, bool pass, int base) __attribute__((always_inline)) {
+      bool moved = false;
+      ConeBound CB;
+      CB.cax = cax; CB.cay = cay; CB.caz = caz; CB.cosT = cosT; CB.sinT = sinT;
+      CB.dcx = dcx; CB.dcy = dcy; CB.dcz = dcz;
+      CB.ehx = ehx; CB.ehy = ehy; CB.ehz = ehz; CB.evx = evx; CB.evy = evy; CB.evz = evz;
+      CB.cam_round = cam_round; CB.dlen_max = dlen_max; CB.reach_max = reach_max;
+      if (PAIRS && pairs_on) {
+        // the lane's triangle: its three functions at this tile (value at the tile's middle + error bound, step per
+        // column, step per row); functions that hold everywhere when it has no set-up
+        float F[9] = {3.0e38f, 0.0f, 0.0f, 3.0e38f, 0.0f, 0.0f, 3.0e38f, 0.0f, 0.0f};
+        const int ti = base >= 0 ? base + lane : i;
+        bool plain = false; // the lane's triangle has no set-up
+        if (pass) {
+          const float4 *su = tri_setup + 4 * size_t(ti);
+          const float4 s3 = su[3];
+          plain = s3.w == 0.0f;
+          float own[3] = {0.0f, 0.0f, 0.0f};
+          if (s3.w == 2.0f) pass = setup_bound_at_tile(sc, cam, CB, ti, own); // no bounding ball: the bound's second part from the tile
+          if (!plain && pass) {
+            if (s3.z * (1.0f - 1e-4f) > reach_max) pass = false; // beyond the tile's depth bound (NaN: never culls)
+            // the tile's middle (column 3.5, row 3.5 of its pixels: the functions are affine) from the reference pixel
+            const float ddx = (float(tile_x * TW) + 3.5f) - s3.x, ddy = (float(grow0) + 3.5f) - s3.y;
+#pragma unroll
+            for (int e = 0; e < 3; ++e) {
+              const float4 q = su[e];
+              const float S = __builtin_fmaf(ddx, q.y, __builtin_fmaf(ddy, q.z, q.x));
+              const float span = 3.5f * (fabsf(q.y) + fabsf(q.z)); // the pixels lie within 3.5 columns and rows of the middle
+              // fp32 from the reference pixel to here (4e-7 of the terms) and from here to a pixel (2e-6: sixteen times what it can be)
+              const float g = (q.w + own[e]) + __builtin_fmaf(4e-7f, fabsf(q.x) + fabsf(ddx * q.y) + fabsf(ddy * q.z), 2e-6f * (fabsf(S) + span));
+              if (__builtin_fmaf(span, 1.0001f, S) + g < 0.0f) pass = false; // no pixel of the tile passes edge e
+              F[3 * e] = S + g; F[3 * e + 1] = q.y; F[3 * e + 2] = q.z;
+            }
+          }
+        }
+        if (__any(plain)) { // (the loose triangles, mostly: they come in batches of their own)
+          if (__popcll(__ballot(pass && plain)) >= TRI_REFINE_MIN && pass && plain)
+            pass = base >= 0 ? triangle_may_be_hit<false>(sc, cam, CB, i) : triangle_may_be_hit<true>(sc, cam, CB, i);
+        }
+        const unsigned long long mask = __ballot(pass);
+        const int total = __popcll(mask);
+        n_clusters++; n_exact += total;
+        // the survivors hand their functions and numbers to the pixels through LDS, PK_SLOTS of them at a time
+        // ([wave][slot][12 floats]: a team's tile that one member renders alone still holds the whole workgroup's LDS,
+        // and with 64 slots per wave that capped a CU at six tiles)
+        const int rank = __builtin_amdgcn_mbcnt_hi(uint32_t(mask >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(mask), 0u)); // survivors below this lane
+        for (int c0 = 0; c0 < total; c0 += PK_SLOTS) {
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); // (the previous slots have been read)
+          if (pass && rank >= c0 && rank < c0 + PK_SLOTS) {
+            float4 *w = pk_fn + (wslot * PK_SLOTS + (rank - c0)) * 3;
+            w[0] = make_float4(F[0], F[1], F[2], F[3]);
+            w[1] = make_float4(F[4], F[5], F[6], F[7]);
+            w[2] = make_float4(F[8], __int_as_float(ti), 0.0f, 0.0f);
+          }
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+          __builtin_amdgcn_wave_barrier();
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+          const int m = min(PK_SLOTS, total - c0);
+          for (int k = 0; k < m; ++k) {
+            const float4 *r = pk_fn + (wslot * PK_SLOTS + k) * 3; // one survivor: the same address in every lane
+            const float4 f0 = r[0], f1 = r[1], f2 = r[2];
+            const float e0 = __builtin_fmaf(pk_a, f0.y, __builtin_fmaf(pk_b, f0.z, f0.x));
+            const float e1 = __builtin_fmaf(pk_a, f1.x, __builtin_fmaf(pk_b, f1.y, f0.w));
+            const float e2 = __builtin_fmaf(pk_a, f1.w, __builtin_fmaf(pk_b, f2.x, f1.z));
+            const bool covered = !(fminf(fminf(e0, e1), e2) < 0.0f); // (NaN: never excludes)
+            const int ncov = __popcll(__ballot(covered));
+            if (ncov > PK_FAT) {
+              // most of the tile: one test for all pixels costs what one more entry in every list would, without the gathers
+              moved |= exact_pass(__builtin_amdgcn_readfirstlane(__float_as_int(f2.y)));
+            } else if (covered) {
+              pk_list[(wslot * PK_CAP + pk_n) * 64 + lane] = (uint32_t)__float_as_int(f2.y);
+              pk_n++;
+            }
+            if (__any(pk_n >= PK_CAP)) pk_flush(); // a full list
+          }
+        }
+        if (NW == 1 && __any(moved)) refresh_reach();
+        return;
+      }
+      if (HIER && __popcll(__ballot(pass)) >= TRI_REFINE_MIN && pass)
+        pass = base >= 0 ? triangle_may_be_hit<false>(sc, cam, CB, i) : triangle_may_be_hit<true>(sc, cam, CB, i);
       unsigned long long mask = __ballot(pass);
       n_clusters++; n_exact += __popcll(mask);
       while (mask) {
         const int j = __builtin_ctzll(mask);
         mask &= mask - 1;
-        const int tj = base >= 0 ? base + j : __builtin_amdgcn_readlane(i, j);  // lane j's triangle
-        const float *q = sc.tri_rec + 16 * size_t(tj);   // wave-uniform address: one s_load_dwordx16
-        const float pnx = q[0], pny = q[1], pnz = q[2], kp = q[3];
-        const float num = kp - dot3(cam.ox, cam.oy, cam.oz, pnx, pny, pnz);
-        const int obj = sc.tri_obj[tj];
-#pragma unroll
-        for (int p = 0; p < P; ++p) {
-          const float rdn = dot3(dx[p], dy[p], dz[p], pnx, pny, pnz);
-          const float t = num / rdn;
-          // the three edge tests only matter in lanes whose t is in range and could still win; no such lane
-          // in the wave (the triangle lies behind what the tile already hit, or behind the camera): skip them
-          const bool cand = (rdn != 0.0f) & (0.01f <= t) & (t <= best_t[p]);
-          if (!__any(cand)) continue;
-          const float px = cam.ox + t * dx[p], py = cam.oy + t * dy[p], pz = cam.oz + t * dz[p];
-          const float e0 = dot3(q[4], q[5], q[6], px, py, pz) - q[7];
-          const float e1 = dot3(q[8], q[9], q[10], px, py, pz) - q[11];
-          const float e2 = dot3(q[12], q[13], q[14], px, py, pz) - q[15];
-          const bool hit = (rdn != 0.0f) & (e0 > -1e-6f) & (e1 > -1e-6f) & (e2 > -1e-6f) & (0.01f <= t) & (t <= MRT_INF);
-          if (hit) {
-            if (t < best_t[p] || (t == best_t[p] && t < MRT_INF && obj < best_obj[p])) {
-              best_t[p] = t; best_obj[p] = obj; best_prim[p] = ns + tj; moved = true;
-            }
-          }
-        }
+        moved |= exact_pass(base >= 0 ? base + j : __builtin_amdgcn_readlane(i, j)); // lane j's triangle
       }
       if (NW == 1 && __any(moved)) refresh_reach();
     };
@@ -635,6 +912,7 @@ void render_cull_kernel(RenderArgs A)
       }
     }
 
+    pk_flush(); // (PAIRS: the pairs still noted)
     if (NW > 1 && !solo) {
       // the team's closest hit: the minimum of the members' (t, object) under the same rule as inside a member
       tm_t[member * 64 + lane] = best_t[0]; tm_obj[member * 64 + lane] = best_obj[0]; tm_prim[member * 64 + lane] = best_prim[0];
@@ -1622,7 +1900,44 @@ static hipError_t launch_cull(RenderArgs &A, hipStream_t stream)
   return hipGetLastError();
 }
 
-size_t loose_scratch_bytes(const RenderArgs &A) { return loose_bytes(A) + bins_bytes(A); }
+// the triangles' set-up (tri_setup_kernel): for the kernel that keeps lists of (pixel, triangle) pairs -- a hierarchy, one
+// sample per pixel, teams dealing leaves.  MRT_PAIRS=0 in the environment: off (every survivor of the
+// refinement is tested for all pixels of its tile, as before round 3's last change)
+static bool setup_applies(const RenderArgs &A)
+{
+  static const bool on = !(getenv("MRT_PAIRS") && atoi(getenv("MRT_PAIRS")) == 0);
+  const bool hier = A.sc.ncs > 1 || A.sc.nct > 1;
+  return on && hier && A.sc.nt > 0 && A.spp == 1 && team_mode(A) == 4;
+}
+static size_t setup_bytes(const RenderArgs &A) { return setup_applies(A) ? size_t(A.sc.nt) * SETUP_FLOATS * 4 : 0; }
+static bool make_setup_cam(const RenderArgs &A, SetupCam &C)
+{
+  const DevCamera &c = A.cam;
+  const double ul[3] = {c.ux, c.uy, c.uz}, h[3] = {c.hx, c.hy, c.hz}, v[3] = {c.vx, c.vy, c.vz}, o[3] = {c.ox, c.oy, c.oz};
+  double g[3], dlmax = 0.0;
+  for (int k = 0; k < 3; ++k) { C.ul[k] = ul[k]; C.h[k] = h[k]; C.v[k] = v[k]; C.o[k] = o[k]; g[k] = ul[k] - o[k]; }
+  // inverse of the matrix with columns (h, v, g): rows = cross products over the determinant
+  const double cx[3][3] = {{v[1] * g[2] - v[2] * g[1], v[2] * g[0] - v[0] * g[2], v[0] * g[1] - v[1] * g[0]},
+                           {g[1] * h[2] - g[2] * h[1], g[2] * h[0] - g[0] * h[2], g[0] * h[1] - g[1] * h[0]},
+                           {h[1] * v[2] - h[2] * v[1], h[2] * v[0] - h[0] * v[2], h[0] * v[1] - h[1] * v[0]}};
+  const double det = h[0] * cx[0][0] + h[1] * cx[0][1] + h[2] * cx[0][2];
+  const bool ok = std::isfinite(det) && std::fabs(det) > 1e-300;
+  for (int r = 0; r < 3; ++r)
+    for (int k = 0; k < 3; ++k) C.inv[r][k] = ok ? cx[r][k] / det : 0.0; // (a degenerate camera: every reference pixel is the frame's middle)
+  C.W = A.W; C.H = A.H; C.rW = 1.0 / A.W; C.rH = 1.0 / A.H;
+  for (int k = 0; k < 3; ++k)
+    C.r[k] = float(1.5 * 5.9604645e-8 * (3.0 * std::fabs(ul[k]) + 5.0 * std::fabs(h[k]) + 4.0 * std::fabs(v[k]) + std::fabs(o[k])) * 1.0001);
+  for (int a = 0; a < 2; ++a)
+    for (int b = 0; b < 2; ++b) {
+      double d2 = 0.0;
+      for (int k = 0; k < 3; ++k) { const double d = g[k] + a * h[k] + b * v[k]; d2 += d * d; }
+      dlmax = std::max(dlmax, std::sqrt(d2));
+    }
+  C.dl = float(dlmax * 1.001) + 2.0f * camera_rounding(A.cam); // (|ray| is convex over the frame: a corner has the longest)
+  return std::isfinite(C.dl);
+}
+
+size_t loose_scratch_bytes(const RenderArgs &A) { return (loose_bytes(A) + bins_bytes(A) + 255) / 256 * 256 + setup_bytes(A); }
 
 hipError_t launch_render_cull(const RenderArgs &in, hipStream_t stream) { return launch_render_cull(in, nullptr, stream); }
 
@@ -1631,6 +1946,17 @@ hipError_t launch_render_cull(const RenderArgs &in, void *loose_scratch, hipStre
   RenderArgs A = in;
   A.loose_list = nullptr; A.loose_cnt = nullptr;
   A.bin_cnt = nullptr; A.bin_list = nullptr; A.bin_near = nullptr;
+  A.utab = nullptr; // (the cull kernels read the triangles' set-up from here, or null: none)
+  if (loose_scratch && setup_bytes(A)) {
+    SetupCam C;
+    if (make_setup_cam(A, C)) {
+      float4 *su = (float4 *)((char *)loose_scratch + (loose_bytes(A) + bins_bytes(A) + 255) / 256 * 256);
+      hipLaunchKernelGGL(tri_setup_kernel, dim3((unsigned)((A.sc.nt + 255) / 256)), dim3(256), 0, stream, A.sc, C, su);
+      hipError_t e = hipGetLastError();
+      if (e != hipSuccess) return e;
+      A.utab = (const float *)su;
+    }
+  }
   if (loose_scratch && bins_bytes(A)) { // the tiles' bins sit behind the loose triangles' lists; filled by launch_cull<true, 1>
     const size_t tiles = size_t((A.W + 7) / 8) * size_t((A.H + 7) / 8);
     char *b = (char *)loose_scratch + loose_bytes(A);
