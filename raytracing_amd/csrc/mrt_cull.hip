@@ -412,11 +412,20 @@ void render_cull_kernel(RenderArgs A)
   // and the pixels' lists of triangles still to be tested, [wave][entry][pixel]
   constexpr bool PAIRS = HIER && P == 1 && !MULTI && NW > 1 && !LSPLIT; // (a wave on its own: 25 more registers, a wave per SIMD less -- 10k spheres 0.32 -> 0.38 ms)
   constexpr int PK_WAVES = NWS;
-  constexpr int PK_CAP = 4;
-  constexpr int PK_SLOTS = 16;
+#ifndef MRT_PK_CAP
+#define MRT_PK_CAP 4    // entries of a pixel's list
+#endif
+#ifndef MRT_PK_SLOTS
+#define MRT_PK_SLOTS 16 // survivors of a batch that hand their functions over at a time
+#endif
+#ifndef MRT_PK_FAT
+#define MRT_PK_FAT 32   // a survivor that more pixels than this cannot exclude is tested the usual way
+#endif
+  constexpr int PK_CAP = MRT_PK_CAP;
+  constexpr int PK_SLOTS = MRT_PK_SLOTS;
   __shared__ float4 pk_fn[PAIRS ? PK_WAVES * PK_SLOTS * 3 : 1];
   __shared__ uint32_t pk_list[PAIRS ? PK_WAVES * PK_CAP * 64 : 1];
-  constexpr int PK_FAT = 32;                 // a triangle that more pixels than this cannot exclude is tested the usual way
+  constexpr int PK_FAT = MRT_PK_FAT;
   // (the set-up lives behind RenderArgs.utab, which only the small-scene kernel reads: the arguments are at their 4 KB limit)
   [[maybe_unused]] const float4 *tri_setup = PAIRS ? reinterpret_cast<const float4 *>(A.utab) : nullptr;
   [[maybe_unused]] const bool pairs_on = PAIRS && tri_setup != nullptr; // no set-up (no scratch: the allocation-free entry point): the usual way

@@ -546,6 +546,40 @@ def test_grazing_terrains_against_brute_force(gpu_ctx, seed, shift, scale):
         gpu_ctx.set_cull(1)
 
 
+@pytest.mark.parametrize("seed,shift,scale", [(110007, 0.0, 1.0), (110012, 0.0, 1.0), (120003, 3e4, 1.0)])
+def test_pixel_triangle_pairs_of_the_team_kernel(gpu_ctx, seed, shift, scale):
+    """Teams dealing leaves keep lists of (pixel, triangle) pairs from a per-frame triangle set-up and test 64 different
+    pairs per pass (mrt_cull.hip PAIRS).  Grazing terrains with long lists per pixel: the whole frame and
+    the frame put together from the strips of three ranks -- one of them holding two shares -- against the brute-force
+    kernel bit for bit, counters included; the set-up depends on the camera, so a second view follows on the same scene."""
+    spec, W, H = _grazing_terrain(seed, shift, scale)
+    gpu_ctx.upload(spec.flatten())
+    views = [spec.cam12(W / H)]
+    c = spec.camera
+    views.append(capi.viewport(tuple(np.add(c["look_from"], (3.0 * scale, 0.5 * scale, -2.0 * scale))), c["look_at"], c["up"],
+                               0.6 * c["vfov"], W / H))
+    try:
+        for cam12 in views:
+            gpu_ctx.set_cull(0)
+            gpu_ctx.set_cull_team(0)
+            ref = gpu_ctx.render(cam12, W, H)
+            gpu_ctx.set_cull(2)
+            gpu_ctx.set_cull_team(4)
+            g = gpu_ctx.render(cam12, W, H)
+            for k in ("id", "t", "rgb"):
+                assert np.array_equal(g[k].view(np.int32), ref[k].view(np.int32)), (seed, k)
+            assert_stats_parity(g["stats"], ref["stats"])
+            # strips: shares 0-1 in one call, shares 2 and 3 each in theirs
+            for rank, span in ((0, 2), (2, 1), (3, 1)):
+                part = gpu_ctx.render(cam12, W, H, rank=rank, num_ranks=4, strip_rows=8, rank_span=span)
+                rows = capi.local_row_index(H, rank, 4, 8, span)
+                for k in ("id", "t", "rgb"):
+                    assert np.array_equal(part[k].view(np.int32), ref[k][rows].view(np.int32)), (seed, rank, k)
+    finally:
+        gpu_ctx.set_cull_team(0)
+        gpu_ctx.set_cull(1)
+
+
 @pytest.mark.parametrize("seed", [3, 11, 29, 57])
 def test_small_scenes_rendered_again_and_again(gpu_ctx, seed):
     """The small-scene launcher tunes the launch order of the tile rows to a view it has seen before (from the
