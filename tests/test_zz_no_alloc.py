@@ -32,7 +32,7 @@ def _same(a, b, what):
         assert np.array_equal(x, y), f"{what}: {k} differs between mrt_render_device_static and mrt_render_device"
 
 
-@pytest.mark.parametrize("scene", ["default", "spheres_3000", "default_brute"])
+@pytest.mark.parametrize("scene", ["default", "spheres_3000", "default_brute", "terrain_teams"])
 def test_static_entry_point_matches_render_device(scene):
     torch = pytest.importorskip("torch")
     ctx = capi.Context(0)
@@ -40,6 +40,10 @@ def test_static_entry_point_matches_render_device(scene):
         if scene == "spheres_3000":          # tile-culling kernel: counters only
             spec = scenes.sphere_field(3000)
             flat, cam_of = spec.flatten(), spec.cam12
+        elif scene == "terrain_teams":       # teams dealing leaves: with scratch, lists of (pixel, triangle) pairs from the
+            spec = scenes.triangle_terrain(120, 80)  # per-frame triangle set-up; without, every survivor for all pixels
+            flat, cam_of = spec.flatten(), spec.cam12
+            ctx.set_cull_team(4)
         else:                                # small-scene kernel: counters + u / v tables
             flat, cam_of = scenes.default_scene()[0], capi.default_viewport
         ctx.upload(flat)
