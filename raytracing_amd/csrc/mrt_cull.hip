@@ -83,6 +83,12 @@ enum { LOOSE_BLOCK_SHIFT = 6, LOOSE_BLOCK = 1 << LOOSE_BLOCK_SHIFT }; // the loo
 // the tiles' bins (bin_primitives_kernel): counters start BIN_HEAD words into bin_cnt (word 0: the near list overflowed;
 // 1, 2: spheres / triangles in the near list), two per tile (spheres, triangles); bin_near holds BIN_NEAR_CAP of each
 enum { BIN_HEAD = 4, BIN_NEAR_CAP = 512 };
+// A long near list makes the lists a loss: every tile tests every entry (300 000 spheres at 4K: the leaf clusters next to
+// the camera are seen on more than BIN_MAX_RECT tiles each, 430 of them end up in the near list, and the frame took 5.8 ms
+// with the lists against 1.6 ms walking).  From this many batches of a kind on, the tiles walk.
+#ifndef MRT_BIN_NEAR_OK
+#define MRT_BIN_NEAR_OK 32
+#endif
 #ifndef MRT_CULL_TEAM_WAVES
 #define MRT_CULL_TEAM_WAVES 1 // 7 fits the team kernels into 72 registers only by spilling to scratch (C4 3 % faster, 0.3 GB of extra writes per frame): left alone
 #endif
@@ -486,8 +492,10 @@ void render_cull_kernel(RenderArgs A)
   if constexpr (HIER && P == 1) {
     if (A.bin_cnt && A.bin_cnt[0] == 0u) { // (word 0: the frame's near list overflowed -- nobody uses the bins)
       const uint32_t cs = A.bin_cnt[BIN_HEAD + 2 * gtile], ct = A.bin_cnt[BIN_HEAD + 2 * gtile + 1];
-      binned_s = cs <= (uint32_t)A.bin_cap;
-      binned_t = ct <= (uint32_t)A.bin_cap;
+      // (... nor a kind whose near list is long, in batches of 64 lanes: a leaf cluster is one, 64 primitives are one)
+      const uint32_t near_ok = A.bin_clusters ? (uint32_t)MRT_BIN_NEAR_OK : 64u * (uint32_t)MRT_BIN_NEAR_OK;
+      binned_s = cs <= (uint32_t)A.bin_cap && A.bin_cnt[1] <= near_ok;
+      binned_t = ct <= (uint32_t)A.bin_cap && A.bin_cnt[2] <= near_ok;
     }
   }
   // SOLO TILES.  A team is there for the tiles that are long jobs; most tiles are not (1M triangles at 4K: the median
@@ -1797,8 +1805,13 @@ static size_t bins_bytes(const RenderArgs &A)
 // 1.60 -> 1.17 ms dealing lights (2.9 ms dealing leaves), 1M triangles 5.4 -> 4.4 ms dealing leaves; 10k spheres under
 // one light are faster without teams (0.41 against 0.94 ms).
 // -> 1: one wave per tile; 4: teams dealing leaves; 5: teams dealing lights.  MRT_OPT_CULL_TEAM (or environment
-// MRT_CULL_TEAM, read once) = 1 | 4 | 5 pins it; 0 = by the scene: lights from 8 lights on, leaves from 100 000
-// primitives on.
+// MRT_CULL_TEAM, read once) = 1 | 4 | 5 pins it; 0 = by the scene: lights from 8 lights on; leaves for scenes of many
+// TRIANGLES PER TILE -- from 64 000 triangles and 2.5 per tile of the frame on.  (Until the end of round 3: from 100 000
+// primitives of either kind.  Measured then, tools/exp_team_threshold.py, one wave against teams in ms: 100k spheres
+// 0.33 / 0.63 at 1080p and 0.76 / 1.98 at 4K, 300k spheres 0.40 / 0.92 at 1080p -- spheres never want teams; terrains at
+// 4K: 122k triangles 0.74 / 1.37, 250k 0.89 / 1.39, 360k 1.00 / 0.98, 490k 1.16 / 1.12, 1M 2.92 / 1.41; at 1080p: 40k 0.23 /
+// 0.21, 90k 0.32 / 0.23, 122k 0.41 / 0.40, 250k 0.53 / 0.32, 360k 0.68 / 0.35, 490k 0.87 / 0.42.  A team is for frames
+// whose time is a few long tiles; 130 000 tiles of a 4K frame hide them behind each other, 32 000 do not.)
 static int team_mode(const RenderArgs &A)
 {
   static const int env = [] {
@@ -1811,7 +1824,9 @@ static int team_mode(const RenderArgs &A)
   if (forced) return forced;
   // (teams dealing lights set the lights' shadow walks up lane-parallel over (light, cluster) pairs: at most 64 clusters)
   if (A.sc.nl >= 8 && A.sc.ncs + A.sc.nct <= 64) return 5;
-  return ((long)A.sc.ns + A.sc.nt >= 100000 || A.sc.nl >= 8) ? 4 : 1;
+  const long tiles = (long)((A.W + 7) / 8) * ((A.H + 7) / 8); // of the whole frame, whatever this rank renders of it
+  const bool dense = A.sc.nt >= 64000 && 2L * A.sc.nt >= 5L * tiles;
+  return (dense || A.sc.nl >= 8) ? 4 : 1;
 }
 
 template <bool HIER, int P>
